@@ -1,0 +1,144 @@
+/*
+ * optex.h — C ABI of liboptex_hip.so: the MI355X (gfx950) implementation of the sliced-optimal-transport
+ * inner loop of JCBrouwer/OptimalTextures.
+ *
+ * The reference has no FFI: its hot path is five plain Python functions.  Each entry point
+ * below names the reference code it replaces (file:line in the reference repository); the Python shim that
+ * keeps the reference signatures is optimaltextures_amd/{optex,histmatch}.py, and INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Every function returns 0 on success or a negative
+ *    OPTEX_E_* code; optex_last_error() returns a thread-local message for the last failure.
+ *  - All pointers are DEVICE pointers (fp32 unless stated) on the device current when the call is made.
+ *    The library never allocates, frees or synchronizes: the caller owns every buffer including scratch
+ *    (`ws`, sized by the *_ws_bytes helpers) and every call is asynchronous on `stream` (a hipStream_t;
+ *    NULL = the legacy default stream).  Calls are therefore stream-ordered, re-entrant and capturable
+ *    in a hipGraph.
+ *  - Feature tensors are "channel-major segments": segment s (one independent texture), channel c,
+ *    pixel i lives at  base + s*seg_stride + c*ld + i  (fp32 elements).  NCHW-contiguous memory is
+ *    (ld = H*W, seg_stride = C*H*W); the reference's pooled layout hist.view(c, -1) (histmatch.py:11,17)
+ *    is (ld = B*H*W, seg_stride = H*W) or simply one segment of n = B*H*W.
+ *  - "pixel-major" (layout = OPTEX_PIXEL_MAJOR) is the reference's NHWC-contiguous [n, C] layout:
+ *    pixel i, channel c at  base + s*seg_stride + i*ld + c.
+ */
+#ifndef OPTEX_H
+#define OPTEX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPTEX_ABI_VERSION 1
+#define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
+
+enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
+enum { OPTEX_CHANNEL_MAJOR = 0, OPTEX_PIXEL_MAJOR = 1 };
+
+int optex_abi_version(void);
+const char* optex_last_error(void);
+/* multiProcessorCount / LDS bytes per block of the current device (diagnostics for bench.py) */
+int optex_device_info(int* n_cu, int* lds_bytes, int* wavefront);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1  rotation / apply GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   OUT[s][m][i] = sum_k At[s][k][m] * (B[s][k][i] - bsub[s][k]) + badd[s][m]          (k ascending, one
+ *   fp32 fma per product: bit-identical to a sequential fmaf chain), then optionally the caller epilogue
+ *   of optex.py:115-117:  OUT += strength * (content - OUT)  (content has OUT's layout and strides).
+ * Replaces:  optex.py:170 `pastiche_feature @ rotation`   (At = R,   B = pastiche)
+ *            optex.py:171 `style_feature @ rotation`      (At = R,   B = style)
+ *            optex.py:175 `matched_pastiche @ rotation.T` (At = R^T, B = matched)
+ *            histmatch.py:27/34/42,44 `T @ hist_t + mu_s`  (At = T^T, bsub = mu_t, badd = mu_s)
+ * At is [K, M] row-major with leading dimension lda; at_seg_stride = 0 shares one matrix between segments.
+ * bsub / badd / content may be NULL; their seg strides are in elements (0 = shared).
+ * ------------------------------------------------------------------------------------------------- */
+int optex_gemm_tn(const float* At, long lda, long at_seg_stride,
+                  const float* B, long ldb, long b_seg_stride, int b_layout,
+                  float* OUT, long ldo, long o_seg_stride, int o_layout,
+                  int M, int K, long n, int n_seg,
+                  const float* bsub, long bsub_seg_stride, const float* badd, long badd_seg_stride,
+                  const float* content, float strength, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K2/K3  cdf mode, histmatch.py:49-69 (cdf_match) + histmatch.py:72-92 (interp), 256 bins.
+ * Stage entry points (each has its own known-answer test) and the whole pipeline.
+ * ------------------------------------------------------------------------------------------------- */
+/* histmatch.py:52-53: per (segment, channel) min and max.  mn/mx are [n_seg, C] fp32. */
+int optex_col_minmax(const float* x, long ld, long seg_stride, long n, int C, int n_seg, float* mn, float* mx,
+                     void* stream);
+/* histmatch.py:57-58: torch.histc(x, 256, lo, hi) per (segment, channel).  lo/hi are [n_seg, C]; hist is
+ * [n_seg, C, 256] uint32 (exact integer counts; the reference holds the same integers in fp32). */
+int optex_col_histc(const float* x, long ld, long seg_stride, long n, int C, int n_seg, const float* lo,
+                    const float* hi, uint32_t* hist, void* stream);
+/* histmatch.py:72-92 on arbitrary 1-D arrays: out[i] = interp(x[i], xp[0..np), fp[0..np)) */
+int optex_interp(const float* x, long nx, const float* xp, const float* fp, long np_, float* out, void* stream);
+
+size_t optex_cdf_ws_bytes(int C, int n_seg);
+/* Whole cdf_match for n_seg independent target segments.  The source has src_n_seg in {1, n_seg} segments
+ * (1 = every target segment is matched to the same source distribution).  `out` may alias `target`.
+ * dbg (NULL or [n_seg, C, 2 + 4*256] fp32) receives lo, hi, hist_t, hist_s, bin_edges, remapped_cdf per
+ * column, the intermediates of histmatch.py:52-67. */
+int optex_cdf_match(const float* target, long ldt, long t_seg_stride, long nt,
+                    const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
+                    int C, int n_seg, float* out, long ldo, long o_seg_stride,
+                    void* ws, float* dbg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K6  sort mode — exact 1-D optimal transport per rotated column (north-star addition; there
+ * is no reference counterpart, the specification is oracle/optex_oracle.c orc_sort_columns/orc_sort_match).
+ * Key order = IEEE totalOrder of the fp32 bit pattern, ties keep pixel order (stable); indices are exact.
+ * ------------------------------------------------------------------------------------------------- */
+size_t optex_sort_ws_bytes(long n, int C, int n_seg);
+/* keys -> out_keys [n_seg, C, n] and out_idx [n_seg, C, n] uint32 (either may be NULL) */
+int optex_sort_columns(const float* keys, long ld, long seg_stride, long n, int C, int n_seg, float* out_keys,
+                       uint32_t* out_idx, void* ws, void* stream);
+size_t optex_sort_match_ws_bytes(long nt, long ns, int C, int n_seg, int src_n_seg);
+/* out[rank_i] = sorted_source[floor((2i+1)*ns / (2*nt))] where rank_i is the pixel holding the i-th smallest
+ * target value of the column. */
+int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt,
+                     const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
+                     int C, int n_seg, float* out, long ldo, long o_seg_stride, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K4  linear modes, histmatch.py:16-22: per-(segment, channel) spatial mean and the centred covariance
+ *   cov = hist @ hist.T / N + eps * I.   pool = 0: one covariance per segment (independent textures);
+ *   pool = 1: the reference's batch semantics — means per segment, ONE covariance pooled over all segments.
+ * mu is [n_seg, C]; cov is [n_seg, C, C] (pool = 0) or [C, C] (pool = 1), fp32.
+ * The C x C factorizations of histmatch.py:24-42 stay on torch.linalg (rocSOLVER); the apply GEMM
+ * `T @ hist_t + mu_s` is optex_gemm_tn with bsub/badd.
+ * ------------------------------------------------------------------------------------------------- */
+size_t optex_linear_stats_ws_bytes(long n, int C, int n_seg);
+int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool, float eps,
+                       float* mu, float* cov, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * R0  rotation generator, optex.py:142-149 -> scipy.stats.special_ortho_group.rvs (Householder chain, fp64).
+ * `normals` holds, per rotation, the N(N+1)/2 - 1 standard normals scipy would draw (host RNG stream kept
+ * on the host so that np.random.seed reproduces the reference's matrices); the O(N^3) accumulation runs on
+ * the device.  Outputs (any may be NULL): R64 [count,N,N] fp64, R32 [count,N,N] fp32 (= optex.py:168's cast),
+ * Rt32 = transposes of R32.  ws: optex_rotation_ws_bytes(N, count).
+ * ------------------------------------------------------------------------------------------------- */
+long optex_rotation_normals(int N);
+size_t optex_rotation_ws_bytes(int N, int count);
+int optex_rotations_from_normals(const double* normals, int N, int count, double* R64, float* R32, float* Rt32,
+                                 void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused hot loop, optex.py:112-117 for the modes that need no host-side factorization (cdf, sort):
+ *   for it in range(iters):  x = ((x @ R_it) matched-to (style @ R_it)) @ R_it^T ; optional content blend
+ * x is [n_seg, C, n] channel-major segments, updated in place; style is [src_n_seg, C, ns].
+ * R32 / Rt32 are [iters, C, C] as produced by optex_rotations_from_normals.
+ * mode: 0 = cdf, 1 = sort.
+ * ------------------------------------------------------------------------------------------------- */
+size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg);
+int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
+                  const float* R32, const float* Rt32, int iters, const float* content, float strength,
+                  void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPTEX_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of liboptex_hip.so (include/optex.h).  There is NO fallback: if the library is missing or no
+MI355X is visible, every op raises."""
+import ctypes
+import os
+
+import torch  # imported BEFORE the CDLL so the library binds to the HIP runtime instance torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liboptex_hip.so")
+ABI_VERSION = 1
+CHANNEL_MAJOR, PIXEL_MAJOR = 0, 1
+
+_c = ctypes
+_P, _L, _I, _F, _SZ = _c.c_void_p, _c.c_long, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/optex.h one to one (tests/test_abi.py checks the export list)
+SIGNATURES = {
+    "optex_abi_version": (_I, []),
+    "optex_last_error": (_c.c_char_p, []),
+    "optex_device_info": (_I, [_P, _P, _P]),
+    "optex_gemm_tn": (_I, [_P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _I, _I, _I, _L, _I, _P, _L, _P, _L, _P, _F, _P]),
+    "optex_col_minmax": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
+    "optex_col_histc": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _P]),
+    "optex_interp": (_I, [_P, _L, _P, _P, _L, _P, _P]),
+    "optex_cdf_ws_bytes": (_SZ, [_I, _I]),
+    "optex_cdf_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _P, _P]),
+    "optex_sort_ws_bytes": (_SZ, [_L, _I, _I]),
+    "optex_sort_columns": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _P]),
+    "optex_sort_match_ws_bytes": (_SZ, [_L, _L, _I, _I, _I]),
+    "optex_sort_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _P]),
+    "optex_linear_stats_ws_bytes": (_SZ, [_L, _I, _I]),
+    "optex_linear_stats": (_I, [_P, _L, _L, _L, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "optex_rotation_normals": (_L, [_I]),
+    "optex_rotation_ws_bytes": (_SZ, [_I, _I]),
+    "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "optex_ot_loop_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I]),
+    "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _I, _P, _F, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and set prototypes (no GPU needed for this step)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C optimaltextures_amd/csrc`). optimaltextures_amd has no CPU fallback.")
+        lib = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.optex_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"liboptex_hip.so ABI {lib.optex_abi_version()} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def lib():
+    """The library, for compute: additionally requires a visible GPU."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("optimaltextures_amd needs an MI355X (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback for the HIP path")
+    return load()
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(load().optex_last_error().decode() or f"liboptex_hip error {rc}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def workspace(nbytes, device):
+    """scratch from torch's caching allocator (stream-ordered reuse, no hipMalloc on the hot path)"""
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

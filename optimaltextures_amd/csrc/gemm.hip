@@ -1,0 +1,319 @@
+// gemm.hip — K1: rotation / apply GEMM on the fp32 matrix cores of gfx950.
+//
+//   OUT[s][m][i] = sum_k At[s][k][m] * (B[s][k][i] - bsub[s][k]) + badd[s][m]   (+ content blend)
+//
+// Replaces optex.py:170,171,175 (the three rotation matmuls) and histmatch.py:27/34/42,44 (T @ hist_t + mu_s).
+// The small left matrix (a rotation, C x C) is shared by all pixels; the big operand is the feature map,
+// kept channel-major ([C, n] rows of contiguous pixels = NCHW memory) so that every kernel downstream
+// (min/max, histogram, LUT apply, sort) streams whole cache lines.
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain.  Lanes 0-31 hold k = 2j, lanes 32-63 hold
+// k = 2j+1 of MFMA step j, steps and K-chunks run in ascending order, one accumulator per output element:
+// the result is bit-identical to   for k in 0..K-1: acc = fmaf(a[k], b[k], acc)   (oracle orc_gemm_tn).
+//
+// Roofline: 2*M*K*n flop against 4*(K + M)*n + 4*K*M bytes; at C = 256 the intensity is 64 flop/B, i.e.
+// MFMA-bound (157 TFLOP/s fp32 matrix peak); below C ~ 80 it turns HBM-bound.
+#include "optex_common.h"
+
+namespace optex {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* At; long lda, at_ss;
+    const float* B;  long ldb, b_ss;
+    float* O;        long ldo, o_ss;
+    int M, K; long n; int n_seg;
+    const float* bsub; long bsub_ss;
+    const float* badd; long badd_ss;
+    const float* content; float strength;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 16;       // K-chunk staged per LDS buffer: 8 MFMA steps of k = 2
+constexpr int NT = 256;      // 4 waves, arranged 2 (m) x 2 (n)
+
+template <int BM, int BN, bool BPM, bool OPM, bool VEC>
+__global__ __launch_bounds__(NT) void gemm_tn_kernel(GemmArgs a) {
+    constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
+    constexpr int BSTR = BPM ? (BK + 1) : BN;   // pixel-major B is staged [pixel][k] with an odd stride
+    constexpr int NA = BK * BM / 4 / NT, NB = BK * BN / 4 / NT;
+    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+
+    __shared__ float As[2][BK * BM];
+    __shared__ float Bs[2][BPM ? BN * (BK + 1) : BK * BN];
+
+    const unsigned nblocks = gridDim.x;
+    const unsigned L = xcd_remap(blockIdx.x, nblocks);
+    const int tm_idx = L % a.tiles_m;
+    const int tn_idx = (L / a.tiles_m) % a.tiles_n;
+    const int seg = L / (a.tiles_m * a.tiles_n);
+    const int m0 = tm_idx * BM;
+    const long n0 = (long)tn_idx * BN;
+
+    const float* __restrict__ At = a.At + (size_t)seg * a.at_ss;
+    const float* __restrict__ Bp = a.B + (size_t)seg * a.b_ss;
+    const float* __restrict__ bsub = a.bsub ? a.bsub + (size_t)seg * a.bsub_ss : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    float4 ra[NA], rb[NB];
+
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = tid + i * NT;
+            const int k = idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
+            const int kk = k0 + k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < a.K) {
+                const float* p = At + (size_t)kk * a.lda + m;
+                if (VEC && m + 3 < a.M) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (m + 0 < a.M) v.x = p[0];
+                    if (m + 1 < a.M) v.y = p[1];
+                    if (m + 2 < a.M) v.z = p[2];
+                    if (m + 3 < a.M) v.w = p[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int idx = tid + i * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!BPM) {
+                const int k = idx / (BN / 4);
+                const long nn = n0 + (idx % (BN / 4)) * 4;
+                const int kk = k0 + k;
+                if (kk < a.K) {
+                    const float* p = Bp + (size_t)kk * a.ldb + nn;
+                    if (VEC && nn + 3 < a.n) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (nn + 0 < a.n) v.x = p[0];
+                        if (nn + 1 < a.n) v.y = p[1];
+                        if (nn + 2 < a.n) v.z = p[2];
+                        if (nn + 3 < a.n) v.w = p[3];
+                    }
+                    if (bsub) {
+                        const float s = bsub[kk];
+                        v.x -= s; v.y -= s; v.z -= s; v.w -= s;
+                        // columns past n hold -s: they only feed outputs that are never stored
+                    }
+                }
+            } else {
+                const int px = idx / (BK / 4);
+                const int kk = k0 + (idx % (BK / 4)) * 4;
+                const long nn = n0 + px;
+                if (nn < a.n) {
+                    const float* p = Bp + (size_t)nn * a.ldb + kk;
+                    if (VEC && kk + 3 < a.K) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (kk + 0 < a.K) v.x = p[0];
+                        if (kk + 1 < a.K) v.y = p[1];
+                        if (kk + 2 < a.K) v.z = p[2];
+                        if (kk + 3 < a.K) v.w = p[3];
+                    }
+                    if (bsub) {
+                        if (kk + 0 < a.K) v.x -= bsub[kk + 0];
+                        if (kk + 1 < a.K) v.y -= bsub[kk + 1];
+                        if (kk + 2 < a.K) v.z -= bsub[kk + 2];
+                        if (kk + 3 < a.K) v.w -= bsub[kk + 3];
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = tid + i * NT;
+            const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
+            *reinterpret_cast<float4*>(&As[buf][k * BM + m]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int idx = tid + i * NT;
+            if (!BPM) {
+                const int k = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[buf][k * BN + nn]) = rb[i];
+            } else {
+                const int px = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
+                float* d = &Bs[buf][px * (BK + 1) + kk];
+                d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nchunks = (a.K + BK - 1) / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < nchunks; kc++) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_global((kc + 1) * BK);
+        const float* as = &As[buf][wm * WM + l31];
+        const float* bs = BPM ? &Bs[buf][(wn * WN + l31) * BSTR] : &Bs[buf][wn * WN + l31];
+#pragma unroll
+        for (int j = 0; j < BK / 2; j++) {
+            const int k = 2 * j + h;
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int t = 0; t < TM; t++) av[t] = as[k * BM + t * 32];
+#pragma unroll
+            for (int t = 0; t < TN; t++) bv[t] = BPM ? bs[t * 32 * BSTR + k] : bs[k * BN + t * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (kc + 1 < nchunks) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* __restrict__ Op = a.O + (size_t)seg * a.o_ss;
+    const float* __restrict__ Cp = a.content ? a.content + (size_t)seg * a.o_ss : nullptr;
+    const float* __restrict__ badd = a.badd ? a.badd + (size_t)seg * a.badd_ss : nullptr;
+    const float strength = a.strength;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) {
+            const long nn = n0 + wn * WN + tn * 32 + l31;
+            const int mb = m0 + wm * WM + tm * 32 + 4 * h;
+            if (nn >= a.n) continue;
+            if (!OPM) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) {
+                        float v = acc[tm][tn][r];
+                        if (badd) v = v + badd[m];
+                        const size_t off = (size_t)m * a.ldo + nn;
+                        if (Cp) {
+                            const float d = Cp[off] - v;
+                            const float sd = strength * d;
+                            v = v + sd;
+                        }
+                        Op[off] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int m = mb + 8 * g;
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        v[q] = acc[tm][tn][g * 4 + q];
+                        if (badd && m + q < a.M) v[q] = v[q] + badd[m + q];
+                    }
+                    const size_t off = (size_t)nn * a.ldo + m;
+                    if (Cp) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (m + q < a.M) {
+                                const float d = Cp[off + q] - v[q];
+                                const float sd = strength * d;
+                                v[q] = v[q] + sd;
+                            }
+                    }
+                    if (VEC && m + 3 < a.M) {
+                        *reinterpret_cast<float4*>(Op + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (m + q < a.M) Op[off + q] = v[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool BPM, bool OPM>
+static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (int)((a.n + BN - 1) / BN);
+    const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
+    if (total <= 0 || total > 0x7fffffffLL) {
+        set_error("optex_gemm_tn: bad grid (%lld tiles)", total);
+        return OPTEX_E_ARG;
+    }
+    if (vec)
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BPM, OPM, true>), dim3((unsigned)total), dim3(NT), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BPM, OPM, false>), dim3((unsigned)total), dim3(NT), 0, st, a);
+    return check_launch("gemm_tn_kernel");
+}
+
+template <bool BPM, bool OPM>
+static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
+    // 128x128 tiles read B once per two m-tiles; fall back to 64x64 when that grid would leave CUs idle.
+    const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
+    if (big >= 2LL * n_cu && a.M > 64) return launch_cfg<128, 128, BPM, OPM>(a, vec, st);
+    return launch_cfg<64, 64, BPM, OPM>(a, vec, st);
+}
+
+int device_cu_count();
+
+}  // namespace optex
+
+using namespace optex;
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int optex_gemm_tn(const float* At, long lda, long at_seg_stride, const float* B, long ldb,
+                             long b_seg_stride, int b_layout, float* OUT, long ldo, long o_seg_stride, int o_layout,
+                             int M, int K, long n, int n_seg, const float* bsub, long bsub_seg_stride,
+                             const float* badd, long badd_seg_stride, const float* content, float strength,
+                             void* stream) {
+    if (!At || !B || !OUT || M <= 0 || K <= 0 || n < 0 || n_seg < 0) {
+        set_error("optex_gemm_tn: null pointer or non-positive size (M=%d K=%d n=%ld n_seg=%d)", M, K, n, n_seg);
+        return OPTEX_E_ARG;
+    }
+    if (n == 0 || n_seg == 0) return OPTEX_OK;
+    if (lda < M || (b_layout == OPTEX_CHANNEL_MAJOR ? ldb < n : ldb < K) ||
+        (o_layout == OPTEX_CHANNEL_MAJOR ? ldo < n : ldo < M)) {
+        set_error("optex_gemm_tn: leading dimension smaller than the row length (lda=%ld ldb=%ld ldo=%ld)", lda, ldb, ldo);
+        return OPTEX_E_ARG;
+    }
+    GemmArgs a;
+    a.At = At; a.lda = lda; a.at_ss = at_seg_stride;
+    a.B = B; a.ldb = ldb; a.b_ss = b_seg_stride;
+    a.O = OUT; a.ldo = ldo; a.o_ss = o_seg_stride;
+    a.M = M; a.K = K; a.n = n; a.n_seg = n_seg;
+    a.bsub = bsub; a.bsub_ss = bsub_seg_stride;
+    a.badd = badd; a.badd_ss = badd_seg_stride;
+    a.content = content; a.strength = strength;
+    const bool bpm = b_layout == OPTEX_PIXEL_MAJOR, opm = o_layout == OPTEX_PIXEL_MAJOR;
+    // float4 paths need 16-byte aligned rows on every operand that is accessed with vectors
+    bool vec = aligned16(At) && lda % 4 == 0 && at_seg_stride % 4 == 0 && aligned16(B) && ldb % 4 == 0 &&
+               b_seg_stride % 4 == 0;
+    if (opm) vec = vec && aligned16(OUT) && ldo % 4 == 0 && o_seg_stride % 4 == 0;
+    hipStream_t st = as_stream(stream);
+    const int n_cu = device_cu_count();
+    if (!bpm && !opm) return launch_layout<false, false>(a, vec, n_cu, st);
+    if (bpm && !opm) return launch_layout<true, false>(a, vec, n_cu, st);
+    if (!bpm && opm) return launch_layout<false, true>(a, vec, n_cu, st);
+    return launch_layout<true, true>(a, vec, n_cu, st);
+}

@@ -1,0 +1,196 @@
+// linear.hip — K4: statistics of the linear modes (histmatch.py:16-22): per-(segment, channel) spatial means and the
+// centred covariance  cov = hist @ hist.T / N + eps * I  as a split-K Gram GEMM on the fp32 matrix cores.
+//
+// The Gram matrix is symmetric: only the upper-triangular 64x64 tile pairs are computed (C(C+64)/2 * n * 2 flop
+// instead of 2*n*C^2) and mirrored in the finalize kernel.  Centring happens while staging tiles into LDS, exactly
+// like the reference centres before the GEMM (no E[x^2] - mu^2 cancellation).  Partials of the K (= pixel) split
+// are reduced in a fixed order, so the result is deterministic.
+#include "optex_common.h"
+
+namespace optex {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int GT = 64;        // Gram output tile (GT x GT), 4 waves as 2 x 2 of one 32x32 MFMA tile each
+constexpr int GK = 32;        // pixels staged per chunk
+constexpr int GSTR = GK + 1;  // odd LDS row stride: conflict-free column reads
+constexpr int G_MAX_SPLITS = 64;
+
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ x, long ld, long seg_stride, long n,
+                                                       int C, float* __restrict__ mu, int vec) {
+    const int col = blockIdx.x, seg = col / C, c = col % C;
+    const float* p = x + (size_t)seg * seg_stride + (size_t)c * ld;
+    double s = 0.0;
+    if (vec) {
+        const long nv = n / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (long i = threadIdx.x; i < nv; i += blockDim.x) {
+            const float4 v = p4[i];
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+        for (long i = nv * 4 + threadIdx.x; i < n; i += blockDim.x) s += (double)p[i];
+    } else {
+        for (long i = threadIdx.x; i < n; i += blockDim.x) s += (double)p[i];
+    }
+    s = wave_sum(s);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) mu[col] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n);
+}
+
+// grid = (tile pairs, splits, n_seg).  part[seg][split][C][C] receives the (ti, tj) tile of this pixel range.
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ x, long ld, long seg_stride, long n, int C,
+                                                   const float* __restrict__ mu, long chunk, int tiles,
+                                                   float* __restrict__ part, int vec) {
+    // decode the upper-triangular pair index
+    int pi = blockIdx.x, ti = 0;
+    while (pi >= tiles - ti) {
+        pi -= tiles - ti;
+        ti++;
+    }
+    const int tj = ti + pi;
+    const int seg = blockIdx.z, split = blockIdx.y;
+    const float* xs = x + (size_t)seg * seg_stride;
+    const float* mus = mu + (size_t)seg * C;
+    const long p_beg = (long)split * chunk, p_end = (p_beg + chunk < n) ? p_beg + chunk : n;
+
+    __shared__ float Xi[2][GT * GSTR], Xj[2][GT * GSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, l31 = lane & 31, h = lane >> 5;
+
+    float4 ri[2], rj[2];
+    auto load_global = [&](long p0) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int idx = tid + q * 256;
+            const int row = idx / (GK / 4), px = (idx % (GK / 4)) * 4;
+            const long pp = p0 + px;
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                const int ch = (which ? tj : ti) * GT + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ch < C) {
+                    const float* p = xs + (size_t)ch * ld + pp;
+                    const float m = mus[ch];
+                    if (vec && pp + 3 < p_end) {
+                        v = *reinterpret_cast<const float4*>(p);
+                        v.x -= m; v.y -= m; v.z -= m; v.w -= m;
+                    } else {
+                        if (pp + 0 < p_end) v.x = p[0] - m;
+                        if (pp + 1 < p_end) v.y = p[1] - m;
+                        if (pp + 2 < p_end) v.z = p[2] - m;
+                        if (pp + 3 < p_end) v.w = p[3] - m;
+                    }
+                }
+                if (which) rj[q] = v; else ri[q] = v;
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int idx = tid + q * 256;
+            const int row = idx / (GK / 4), px = (idx % (GK / 4)) * 4;
+            float* di = &Xi[buf][row * GSTR + px];
+            di[0] = ri[q].x; di[1] = ri[q].y; di[2] = ri[q].z; di[3] = ri[q].w;
+            float* dj = &Xj[buf][row * GSTR + px];
+            dj[0] = rj[q].x; dj[1] = rj[q].y; dj[2] = rj[q].z; dj[3] = rj[q].w;
+        }
+    };
+
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+
+    const long nchunks = (p_end - p_beg + GK - 1) / GK;
+    if (nchunks > 0) {
+        load_global(p_beg);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (long kc = 0; kc < nchunks; kc++) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_global(p_beg + (kc + 1) * GK);
+        const float* ai = &Xi[buf][(wi * 32 + l31) * GSTR];
+        const float* bj = &Xj[buf][(wj * 32 + l31) * GSTR];
+#pragma unroll
+        for (int j = 0; j < GK / 2; j++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[2 * j + h], bj[2 * j + h], acc, 0, 0, 0);
+        if (kc + 1 < nchunks) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+    float* o = part + ((size_t)seg * gridDim.y + split) * C * C;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = ti * GT + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int j = tj * GT + wj * 32 + l31;
+        if (i < C && j < C) o[(size_t)i * C + j] = acc[r];
+    }
+}
+
+// cov[s][i][j] = sum_split part / N + eps * (i == j); lower triangle mirrored from the upper tiles.
+// pool: one covariance over all segments (the reference's batch semantics), N = n * n_seg.
+__global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n_seg, int splits, int pool, float N,
+                                    float eps, float* __restrict__ cov) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.z;
+    if (j >= C) return;
+    // element (i, j) lives in tile (i/GT, j/GT) if that is an upper tile, else read (j, i)
+    const bool upper = (i / GT) <= (j / GT);
+    const int ri = upper ? i : j, rj = upper ? j : i;
+    float sum = 0.f;
+    const int s_beg = pool ? 0 : s, s_end = pool ? n_seg : s + 1;
+    for (int ss = s_beg; ss < s_end; ss++)
+        for (int k = 0; k < splits; k++) sum += part[((size_t)ss * splits + k) * C * C + (size_t)ri * C + rj];
+    float v = __fdiv_rn(sum, N);
+    if (i == j) v = v + eps;
+    cov[(size_t)s * C * C + (size_t)i * C + j] = v;
+}
+
+int device_cu_count();
+
+static int gram_splits(long n, int C, int n_seg) {
+    const int tiles = (C + GT - 1) / GT, pairs = tiles * (tiles + 1) / 2;
+    long want = (2L * device_cu_count() + (long)pairs * n_seg - 1) / ((long)pairs * n_seg);
+    long maxs = (n + 1023) / 1024;
+    if (want > maxs) want = maxs;
+    if (want > G_MAX_SPLITS) want = G_MAX_SPLITS;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+}  // namespace optex
+
+using namespace optex;
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" size_t optex_linear_stats_ws_bytes(long n, int C, int n_seg) {
+    (void)n;
+    return align_up((size_t)n_seg * G_MAX_SPLITS * C * C * sizeof(float), 256);
+}
+
+extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool,
+                                  float eps, float* mu, float* cov, void* ws, void* stream) {
+    if (!x || !mu || !cov || !ws || n <= 0 || C <= 0 || n_seg <= 0 || ld < n) {
+        set_error("optex_linear_stats: bad argument (n=%ld C=%d n_seg=%d ld=%ld)", n, C, n_seg, ld);
+        return OPTEX_E_ARG;
+    }
+    hipStream_t st = as_stream(stream);
+    const int vec = aligned16(x) && ld % 4 == 0 && seg_stride % 4 == 0;
+    hipLaunchKernelGGL(col_mean_kernel, dim3(C * n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, vec);
+    int rc = check_launch("col_mean_kernel");
+    if (rc) return rc;
+    const int tiles = (C + GT - 1) / GT, pairs = tiles * (tiles + 1) / 2;
+    const int splits = gram_splits(n, C, n_seg);
+    long chunk = (n + splits - 1) / splits;
+    chunk = (chunk + GK - 1) / GK * GK;  // chunk starts stay multiples of 4 pixels (float4 loads)
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(gram_kernel, dim3(pairs, splits, n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, chunk,
+                       tiles, part, vec);
+    if ((rc = check_launch("gram_kernel"))) return rc;
+    const float N = pool ? (float)((double)n * n_seg) : (float)n;
+    hipLaunchKernelGGL(cov_finalize_kernel, dim3((C + 63) / 64, C, pool ? 1 : n_seg), dim3(64), 0, st, part, C, n_seg,
+                       splits, pool, N, eps, cov);
+    return check_launch("cov_finalize_kernel");
+}

@@ -1,0 +1,65 @@
+// optex_common.h — shared helpers for the gfx950 kernels behind include/optex.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/optex.h"
+
+namespace optex {
+
+constexpr int kBins = OPTEX_BINS;
+constexpr int kWave = 64;       // CDNA4 wavefront
+constexpr int kNumXcd = 8;      // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bijective XCD-aware remap of a 1-D block id: consecutive logical ids land on the same XCD (and share its L2).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned q = nblocks / kNumXcd, r = nblocks % kNumXcd;
+    const unsigned xcd = bid % kNumXcd, slot = bid / kNumXcd;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// IEEE totalOrder key: unsigned compare of f2key(a), f2key(b) orders floats with -0 < +0.
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// implemented in cdf.hip / sort.hip, shared with the fused loop in ot_loop.hip
+int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
+                   int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
+                   hipStream_t st);
+int sort_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
+                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, hipStream_t st);
+int device_cu_count();
+
+}  // namespace optex

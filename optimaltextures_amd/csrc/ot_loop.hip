@@ -1,0 +1,78 @@
+// ot_loop.hip — the reference's hot loop (optex.py:112-117) for the modes that need no host-side factorization:
+//   for it in range(iters):  x = hist_match(x @ R, style @ R, mode) @ R.T ;  x += strength * (content - x)
+// enqueued back-to-back on one stream from C++ (no Python between launches).  Everything stays channel-major
+// ([segment][channel][pixel] = NCHW memory), so no kernel in the loop transposes anything.
+#include "optex_common.h"
+
+using namespace optex;
+
+namespace {
+struct LoopWs {
+    float* y;    // rotated pastiche [n_seg, C, n]
+    float* ys;   // rotated style    [src_n_seg, C, ns]
+    void* mode_ws;
+    static size_t mode_bytes(int mode, long ns, int C, int n_seg, int src_n_seg) {
+        return mode == 0 ? optex_cdf_ws_bytes(C, n_seg) : optex_sort_match_ws_bytes(0, ns, C, n_seg, src_n_seg);
+    }
+    static size_t bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg) {
+        return align_up((size_t)n_seg * C * n * sizeof(float), 256) +
+               align_up((size_t)src_n_seg * C * ns * sizeof(float), 256) + mode_bytes(mode, ns, C, n_seg, src_n_seg);
+    }
+    LoopWs(void* ws, long n, long ns, int C, int n_seg, int src_n_seg) {
+        char* p = static_cast<char*>(ws);
+        y = reinterpret_cast<float*>(p);
+        p += align_up((size_t)n_seg * C * n * sizeof(float), 256);
+        ys = reinterpret_cast<float*>(p);
+        p += align_up((size_t)src_n_seg * C * ns * sizeof(float), 256);
+        mode_ws = p;
+    }
+};
+}  // namespace
+
+extern "C" size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg) {
+    return LoopWs::bytes(mode, n, ns, C, n_seg, src_n_seg);
+}
+
+extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
+                             const float* R32, const float* Rt32, int iters, const float* content, float strength,
+                             void* ws, void* stream) {
+    if (!x || !style || !R32 || !Rt32 || !ws || n <= 0 || ns <= 0 || C < 2 || n_seg <= 0 || iters < 0) {
+        set_error("optex_ot_loop: bad argument (n=%ld ns=%ld C=%d n_seg=%d iters=%d)", n, ns, C, n_seg, iters);
+        return OPTEX_E_ARG;
+    }
+    if (mode != 0 && mode != 1) {
+        set_error("optex_ot_loop: mode %d (0 = cdf, 1 = sort; the linear modes factorize on the host side)", mode);
+        return OPTEX_E_ARG;
+    }
+    if (src_n_seg != 1 && src_n_seg != n_seg) {
+        set_error("optex_ot_loop: style has %d segments, expected 1 or %d", src_n_seg, n_seg);
+        return OPTEX_E_ARG;
+    }
+    LoopWs w(ws, n, ns, C, n_seg, src_n_seg);
+    hipStream_t st = as_stream(stream);
+    const long xs = (long)C * n, ss = (long)C * ns;
+    for (int it = 0; it < iters; it++) {
+        const float* R = R32 + (size_t)it * C * C;
+        const float* Rt = Rt32 + (size_t)it * C * C;
+        int rc;
+        // optex.py:170  rotated_pastiche = pastiche_feature @ rotation
+        if ((rc = optex_gemm_tn(R, C, 0, x, n, xs, OPTEX_CHANNEL_MAJOR, w.y, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
+                                nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+            return rc;
+        // optex.py:171  rotated_style = style_feature @ rotation
+        if ((rc = optex_gemm_tn(R, C, 0, style, ns, ss, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C, C,
+                                ns, src_n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+            return rc;
+        // optex.py:173  hist_match(rotated_pastiche, rotated_style), in place
+        if (mode == 0)
+            rc = cdf_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr, st);
+        else
+            rc = sort_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, st);
+        if (rc) return rc;
+        // optex.py:175 + 115-117  pastiche = matched @ rotation.T ; content blend
+        if ((rc = optex_gemm_tn(Rt, C, 0, w.y, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
+                                nullptr, 0, nullptr, 0, content, strength, stream)))
+            return rc;
+    }
+    return OPTEX_OK;
+}

@@ -1,0 +1,179 @@
+"""Thin typed wrappers over the C ABI (include/optex.h) working on torch CUDA tensors.
+
+Layout vocabulary: a *segment tensor* is fp32 [S, C, n] — S independent textures (segments), channel-major, n pixels
+per channel contiguous: exactly NCHW memory.  Strided views of it are passed through (ld, seg_stride) without copies.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CHANNEL_MAJOR, PIXEL_MAJOR, check, ptr, stream_ptr, workspace
+
+BINS = 256
+LOOP_MODES = {"cdf": 0, "sort": 1}
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype} (the reference's cdf path is fp32-only too, histmatch.py:59)")
+    return t
+
+
+class Seg:
+    """(tensor, ld, seg_stride, n, C, n_seg) description of channel-major segments inside `base`."""
+
+    __slots__ = ("t", "ld", "ss", "n", "C", "S")
+
+    def __init__(self, t, ld, ss, n, C, S):
+        self.t, self.ld, self.ss, self.n, self.C, self.S = t, int(ld), int(ss), int(n), int(C), int(S)
+
+    @staticmethod
+    def of(x):
+        """x: contiguous [S, C, n]"""
+        x = _f32c(x)
+        assert x.dim() == 3 and x.is_contiguous()
+        S, C, n = x.shape
+        return Seg(x, n, C * n, n, C, S)
+
+    @staticmethod
+    def pooled(x, n_items):
+        """x: contiguous [C, n_items * n] — the reference's hist.view(c, -1); items are sub-ranges of each row"""
+        x = _f32c(x)
+        assert x.dim() == 2 and x.is_contiguous()
+        C, N = x.shape
+        assert N % n_items == 0
+        return Seg(x, N, N // n_items, N // n_items, C, n_items)
+
+
+def gemm_tn(At, B, out, M, K, n, n_seg, *, lda, at_ss=0, ldb, b_ss, b_layout=CHANNEL_MAJOR, ldo, o_ss,
+            o_layout=CHANNEL_MAJOR, bsub=None, bsub_ss=0, badd=None, badd_ss=0, content=None, strength=0.0):
+    check(_lib.lib().optex_gemm_tn(ptr(At), lda, at_ss, ptr(B), ldb, b_ss, b_layout, ptr(out), ldo, o_ss, o_layout,
+                                   M, K, n, n_seg, ptr(bsub), bsub_ss, ptr(badd), badd_ss, ptr(content),
+                                   ctypes.c_float(strength), stream_ptr()))
+    return out
+
+
+def rotate_seg(x, R, out=None):
+    """[S, C, n] channel-major:  out[s] = R^T @ x[s]   == (x_nhwc @ R) in channel-major form (optex.py:170-171)"""
+    S, C, n = x.shape
+    out = torch.empty_like(x) if out is None else out
+    return gemm_tn(R, x, out, C, C, n, S, lda=C, ldb=n, b_ss=C * n, ldo=n, o_ss=C * n)
+
+
+def unrotate_seg(m, Rt, out=None, content=None, strength=0.0):
+    """out[s] = R @ m[s] == (m_nhwc @ R.T) (optex.py:175), optional content blend (optex.py:115-117).  Rt = R.T contiguous."""
+    S, C, n = m.shape
+    out = torch.empty_like(m) if out is None else out
+    return gemm_tn(Rt, m, out, C, C, n, S, lda=C, ldb=n, b_ss=C * n, ldo=n, o_ss=C * n, content=content,
+                   strength=strength)
+
+
+def col_minmax(x):
+    S, C, n = x.shape
+    mn = torch.empty((S, C), dtype=torch.float32, device=x.device)
+    mx = torch.empty_like(mn)
+    check(_lib.lib().optex_col_minmax(ptr(_f32c(x)), n, C * n, n, C, S, ptr(mn), ptr(mx), stream_ptr()))
+    return mn, mx
+
+
+def col_histc(x, lo, hi):
+    S, C, n = x.shape
+    hist = torch.empty((S, C, BINS), dtype=torch.int32, device=x.device)
+    check(_lib.lib().optex_col_histc(ptr(_f32c(x)), n, C * n, n, C, S, ptr(_f32c(lo).contiguous()),
+                                     ptr(_f32c(hi).contiguous()), ptr(hist), stream_ptr()))
+    return hist
+
+
+def interp(x, xp, fp):
+    x, xp, fp = _f32c(x).contiguous(), _f32c(xp).contiguous(), _f32c(fp).contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().optex_interp(ptr(x), x.numel(), ptr(xp), ptr(fp), xp.numel(), ptr(out), stream_ptr()))
+    return out
+
+
+def cdf_match_seg(t: Seg, s: Seg, out: Seg = None, debug=False):
+    lib = _lib.lib()
+    assert t.C == s.C
+    if out is None:
+        o = torch.empty((t.S, t.C, t.n), dtype=torch.float32, device=t.t.device)
+        out = Seg.of(o)
+    ws = workspace(lib.optex_cdf_ws_bytes(t.C, t.S), t.t.device)
+    dbg = torch.empty((t.S, t.C, 2 + 4 * BINS), dtype=torch.float32, device=t.t.device) if debug else None
+    check(lib.optex_cdf_match(ptr(t.t), t.ld, t.ss, t.n, ptr(s.t), s.ld, s.ss, s.n, s.S, t.C, t.S, ptr(out.t), out.ld,
+                              out.ss, ptr(ws), ptr(dbg), stream_ptr()))
+    if debug:
+        d = dict(lo=dbg[..., 0], hi=dbg[..., 1], hist_t=dbg[..., 2:2 + BINS], hist_s=dbg[..., 2 + BINS:2 + 2 * BINS],
+                 bin_edges=dbg[..., 2 + 2 * BINS:2 + 3 * BINS], remapped=dbg[..., 2 + 3 * BINS:])
+        return out.t, d
+    return out.t
+
+
+def sort_columns(x, want_keys=True, want_idx=True):
+    lib = _lib.lib()
+    S, C, n = x.shape
+    ok = torch.empty((S, C, n), dtype=torch.float32, device=x.device) if want_keys else None
+    oi = torch.empty((S, C, n), dtype=torch.int32, device=x.device) if want_idx else None
+    ws = workspace(lib.optex_sort_ws_bytes(n, C, S), x.device)
+    check(lib.optex_sort_columns(ptr(_f32c(x)), n, C * n, n, C, S, ptr(ok), ptr(oi), ptr(ws), stream_ptr()))
+    return ok, oi
+
+
+def sort_match_seg(t: Seg, s: Seg, out: Seg = None):
+    lib = _lib.lib()
+    assert t.C == s.C
+    if out is None:
+        out = Seg.of(torch.empty((t.S, t.C, t.n), dtype=torch.float32, device=t.t.device))
+    ws = workspace(lib.optex_sort_match_ws_bytes(t.n, s.n, t.C, t.S, s.S), t.t.device)
+    check(lib.optex_sort_match(ptr(t.t), t.ld, t.ss, t.n, ptr(s.t), s.ld, s.ss, s.n, s.S, t.C, t.S, ptr(out.t), out.ld,
+                               out.ss, ptr(ws), stream_ptr()))
+    return out.t
+
+
+def linear_stats(x: Seg, pool, eps=1.0):
+    """histmatch.py:16-22.  returns mu [S, C], cov [S, C, C] (pool=False) or [C, C] (pool=True)"""
+    lib = _lib.lib()
+    dev = x.t.device
+    mu = torch.empty((x.S, x.C), dtype=torch.float32, device=dev)
+    cov = torch.empty((x.C, x.C) if pool else (x.S, x.C, x.C), dtype=torch.float32, device=dev)
+    ws = workspace(lib.optex_linear_stats_ws_bytes(x.n, x.C, x.S), dev)
+    check(lib.optex_linear_stats(ptr(x.t), x.ld, x.ss, x.n, x.C, x.S, int(bool(pool)), ctypes.c_float(eps), ptr(mu),
+                                 ptr(cov), ptr(ws), stream_ptr()))
+    return mu, cov
+
+
+def rotation_normals(N):
+    return int(_lib.load().optex_rotation_normals(int(N)))
+
+
+def rotations_from_normals(normals, N, count, device, want64=False):
+    """normals: host float64 array [count, N(N+1)/2-1] (numpy) or device tensor.  Returns (R32, Rt32[, R64])."""
+    lib = _lib.lib()
+    per = rotation_normals(N)
+    if not torch.is_tensor(normals):
+        normals = torch.from_numpy(np.ascontiguousarray(normals, dtype=np.float64).reshape(count, per))
+    nd = normals.to(device=device, dtype=torch.float64, non_blocking=True).contiguous()
+    R32 = torch.empty((count, N, N), dtype=torch.float32, device=device)
+    Rt32 = torch.empty_like(R32)
+    R64 = torch.empty((count, N, N), dtype=torch.float64, device=device) if want64 else None
+    ws = workspace(lib.optex_rotation_ws_bytes(N, count), device)
+    check(lib.optex_rotations_from_normals(ptr(nd), N, count, ptr(R64), ptr(R32), ptr(Rt32), ptr(ws), stream_ptr()))
+    return (R32, Rt32, R64) if want64 else (R32, Rt32)
+
+
+def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0):
+    """optex.py:112-117 fused on device for mode in {"cdf", "sort"}; x [S, C, n] is updated IN PLACE."""
+    lib = _lib.lib()
+    S, C, n = x.shape
+    Ss, Cs, ns = style.shape
+    assert Cs == C and x.is_contiguous() and style.is_contiguous()
+    iters = R32.shape[0]
+    assert R32.shape == (iters, C, C) and Rt32.shape == (iters, C, C) and R32.is_contiguous() and Rt32.is_contiguous()
+    if content is not None:
+        assert content.shape == x.shape and content.is_contiguous()
+    m = LOOP_MODES[mode]
+    ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss), x.device)
+    check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), iters,
+                            ptr(content), ctypes.c_float(strength), ptr(ws), stream_ptr()))
+    return x

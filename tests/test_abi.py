@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly what include/optex.h declares,
+the ctypes prototypes cover every export, and the product path fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from optimaltextures_amd import _lib
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "optex.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(optex_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/optex.h but not exported by liboptex_hip.so"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes and header disagree"
+    assert lib.optex_abi_version() == 1
+
+
+def test_size_helpers_need_no_gpu():
+    lib = _lib.load()
+    assert lib.optex_rotation_normals(256) == 256 * 257 // 2 - 1 == 32895
+    assert lib.optex_cdf_ws_bytes(256, 4) > 4 * 256 * (4 * 4 + 2 * 256 * 4 + 3 * 256 * 4) - 1
+    assert lib.optex_ot_loop_ws_bytes(0, 16384, 12288, 256, 2, 1) >= (2 * 16384 + 12288) * 256 * 4
+
+
+def test_argument_errors_are_reported_without_launching():
+    lib = _lib.load()
+    rc = lib.optex_gemm_tn(None, 0, 0, None, 0, 0, 0, None, 0, 0, 0, 4, 4, 16, 1, None, 0, None, 0, None, 0.0, None)
+    assert rc == -1 and b"optex_gemm_tn" in lib.optex_last_error()
+    rc = lib.optex_rotations_from_normals(None, 1, 1, None, None, None, None, None)
+    assert rc == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    import optimaltextures_amd as ot
+    x = torch.rand(1, 8, 8, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ot.hist_match(x, x, "cdf")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ot.interp(torch.rand(4), torch.rand(4), torch.rand(4))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "optimaltextures_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboptex_oracle" not in text, f
