@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric: 512^2 textures/sec (relu3_1, default iters) on N MI355X.
+
+A step = synthesising B independent 512^2 textures per GPU end to end: 5 multi-resolution passes (256..512), each
+VGG-encode (relu3_1, C = 256, --no_pca) -> 13/12/10/9/8 sliced-OT iterations (52 in total, the reference's default
+schedule for that layer, util.py:68-86 / optex.py:112) -> decode.  The hot path (rotations, histogram/sort matching)
+runs in the HIP kernels of liboptex_hip.so; VGG encode/decode stay on PyTorch-ROCm as the north star scopes them.
+Synthetic data: seeded random style image and random-init VGG weights of the reference's architecture (no assets on
+the GPU box); all inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Rank 0 prints ONE JSON line.  `roofline` describes the kernel class that took the most time in the timed steps,
+measured live with HIP events on the launch stream (optex_prof_*); `cpu_baseline` times the CPU oracle (+ torch-CPU
+VGG) on one texture of the same workload on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from optimaltextures_amd import dist as otdist  # noqa: E402
+from optimaltextures_amd import ops  # noqa: E402
+from optimaltextures_amd.driver import OptimalTexture  # noqa: E402
+from optimaltextures_amd.util import get_iters_and_sizes, get_size, layer_iters, resize  # noqa: E402
+
+SIZE, PASSES, ITERS, LAYER = 512, 5, 500, 3
+PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS = 8000.0, 157.3  # MI355X_MICROARCH.md chip-level parameters
+MFMA_CLASSES = ("gemm_tn", "gram")
+
+
+def synthetic_style(device, seed=0):
+    """style/graffiti.jpg loads as [1,3,736,512] at --size 512 (util.py:29,33-42); same shape, smooth random content"""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, 3, 46, 32, generator=g)
+    img = torch.nn.functional.interpolate(low, size=(736, 512), mode="bicubic", align_corners=False)
+    return (img + 0.05 * torch.randn(1, 3, 736, 512, generator=g)).clamp(0, 1).to(device)
+
+
+def make_texturizer(hist_mode, device):
+    return OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode=hist_mode, no_pca=True, layers=(LAYER,),
+                          independent=True).to(device).eval()
+
+
+def roofline_of(name, rec):
+    ms, launches = rec["ms"], max(rec["launches"], 1)
+    if name in MFMA_CLASSES:
+        achieved, peak, unit, bound = rec["flops"] / (ms * 1e9), PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"
+    else:
+        achieved, peak, unit, bound = rec["bytes"] / (ms * 1e6), PEAK_HBM_GBS, "GB/s", "hbm"
+    return {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+            "frac": round(achieved / peak, 4), "traffic": None, "launches": rec["launches"],
+            "avg_us": round(1e3 * ms / launches, 3)}
+
+
+def cpu_baseline(hist_mode, threads):
+    """One texture of the same workload on the host: torch-CPU VGG + the CPU oracle for every OT iteration."""
+    from oracle import oracle as orc
+    from optimaltextures_amd.vgg import Decoder, Encoder
+    torch.set_num_threads(threads)
+    orc.set_num_threads(threads)
+    enc, dec = Encoder(LAYER).eval(), Decoder(LAYER).eval()
+    style = synthetic_style("cpu")
+    table, sizes = get_iters_and_sizes(SIZE, ITERS, PASSES, True)
+    rng = orc.LegacyRNG(1000)
+    torch.manual_seed(0)
+    pastiche = torch.rand(1, 3, SIZE, SIZE)
+    t0 = time.perf_counter()
+    n_iter = 0
+    with torch.inference_mode():
+        for p, size in enumerate(sizes):
+            if pastiche.shape[-2] != size and pastiche.shape[-1] != size:
+                sty = resize(style, size=get_size(size, 1.0, style.shape[2], style.shape[3]))
+                pastiche = resize(pastiche, size=(size, size))
+            else:
+                sty = style
+            sf = enc.features(sty)[0].reshape(256, -1).numpy()
+            feat = enc.features(pastiche)
+            _, c, h, w = feat.shape
+            x = feat[0].reshape(c, h * w).numpy()
+            for _ in range(layer_iters(table, p, 5 - LAYER)):
+                R = orc.random_rotation(c, rng).astype(np.float32)
+                rp, rs = orc.rotate_cm(x, R), orc.rotate_cm(sf, R)
+                x = orc.unrotate_cm(orc.hist_match_cm(rp, 1, rs, 1, hist_mode), R)
+                n_iter += 1
+            pastiche = dec.decode(torch.from_numpy(x).view(1, c, h, w))
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "textures/s", "cores": threads, "kind": "port",
+            "sample": f"1 texture 512^2 relu3_1 C=256 {n_iter} OT iterations ({hist_mode}) + torch-CPU VGG encode/decode, "
+                      f"{dt:.2f} s wall", "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="independent textures per GPU per step")
+    ap.add_argument("--hist_mode", type=str, default="cdf", choices=["cdf", "sort", "chol", "pca", "sym"])
+    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym", help="one extra step each (N = 1 only)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
+    args = ap.parse_args()
+
+    rank, world, device = otdist.init_distributed()
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode: the VGG convs are the largest non-hot-path cost
+
+    B = args.batch
+    style = synthetic_style(device)
+    tex = make_texturizer(args.hist_mode, device)
+    tex.rng = np.random.RandomState(1000 + rank)  # one rotation sequence per rank and step, shared by its B textures
+    if world > 1:
+        tex.style_sync = otdist.StyleSync(device)  # rank 0 encodes the style, RCCL broadcast per (pass, layer)
+    gen = torch.Generator(device=device).manual_seed(rank)
+
+    def step(model):
+        pastiche = torch.rand((B, 3, SIZE, SIZE), device=device, generator=gen)
+        return model.forward(pastiche, [style])
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            step(tex)
+        torch.cuda.synchronize()
+        otdist.barrier()
+        torch.cuda.synchronize()
+        if not args.no_kernel_timing:
+            ops.profile_collect()
+            ops.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(tex)
+        torch.cuda.synchronize()
+        otdist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ops.profile_enable(False)
+        prof = {} if args.no_kernel_timing else ops.profile_collect()
+        assert torch.isfinite(out).all()
+    elapsed = otdist.all_reduce_max(elapsed, device)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = B * world * args.steps / elapsed
+
+    result = {
+        "metric": "512^2 textures/sec (relu3_1, default iters)", "value": round(value, 3), "unit": "textures/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{B} independent 512^2 textures per GPU per step, VGG relu3_1 only, C=256 (no_pca), "
+                               f"5 passes 256..512, 52 OT iterations (default iters=500), hist_mode={args.hist_mode}, "
+                               "style 736x512 synthetic, random-init VGG weights",
+                   "textures_per_gpu_per_step": B, "hist_mode": args.hist_mode, "parallelism": f"textures x{world}",
+                   "rotation_sharing": "one sequence per rank and step"},
+    }
+    if prof:
+        kernels = sorted((roofline_of(k, v) for k, v in prof.items() if v["ms"] > 0), key=lambda r: -r["avg_us"] * r["launches"])
+        result["roofline"] = {k: v for k, v in kernels[0].items()}
+        result["kernels"] = kernels
+        hot_ms = sum(v["ms"] for v in prof.values()) / args.steps
+        result["hot_path_ms_per_step"] = round(hot_ms, 3)
+        result["other_ms_per_step"] = round(ms_per_step - hot_ms, 3)  # VGG encode/decode, resizes, style encode, gaps
+    if world > 1 and tex.style_sync is not None:
+        result["style_broadcast_bytes_per_step"] = tex.style_sync.bytes_moved // (args.warmup + args.steps)
+
+    if world == 1:
+        by_mode = {args.hist_mode: round(value, 3)}
+        with torch.inference_mode():
+            for mode in [m for m in args.other_modes.split(",") if m and m != args.hist_mode]:
+                m = make_texturizer(mode, device)
+                m.rng = np.random.RandomState(1000)
+                step(m)  # warm-up (MIOpen/rocSOLVER handles)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step(m)
+                torch.cuda.synchronize()
+                by_mode[mode] = round(B / (time.perf_counter() - t0), 3)
+        result["textures_per_s_by_hist_mode"] = by_mode
+        if not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            result["cpu_baseline"] = cpu_baseline(args.hist_mode, threads)
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,17 @@ int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, lon
                   const float* R32, const float* Rt32, int iters, const float* content, float strength,
                   void* ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Measurement (no reference counterpart; the reference only wall-clocks forward(), optex.py:285-289).
+ * When enabled, every kernel launch above is bracketed by HIP events recorded on its own stream and tallied
+ * per kernel class together with its ALGORITHMIC flops / bytes.  optex_prof_collect is the only
+ * blocking call of the library: it waits for the recorded events, returns per-class totals and resets them.
+ * ------------------------------------------------------------------------------------------------- */
+int optex_prof_enable(int on);
+int optex_prof_num_classes(void);
+const char* optex_prof_class_name(int cls);
+int optex_prof_collect(int n_classes, double* ms, long long* launches, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Command line of the MI355X build: same flags and defaults as the reference's optex.py:222-244, plus
+--layers / --models_dir / --independent / --np_seed (extensions; the reference hard-codes all five layers, loads
+weights from ./models and leaves numpy's RNG — which drives the rotations — unseeded)."""
+import argparse
+from time import time
+
+import numpy as np
+import torch
+
+from optimaltextures_amd import dist as otdist
+from optimaltextures_amd.driver import OptimalTexture
+from optimaltextures_amd.util import load_styles, maybe_load_content, save_image
+
+
+def required_length(nmin, nmax):
+    class RequiredLength(argparse.Action):
+        def __call__(self, parser, args, values, option_string=None):
+            if not nmin <= len(values) <= nmax:
+                raise argparse.ArgumentTypeError(f'argument "{self.dest}" requires between {nmin} and {nmax} arguments')
+            setattr(args, self.dest, values)
+
+    return RequiredLength
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Optimal-transport texture synthesis on MI355X")
+    p.add_argument("-s", "--style", type=str, nargs="+", action=required_length(1, 2), default=["style/graffiti.jpg"])
+    p.add_argument("-c", "--content", type=str, default=None)
+    p.add_argument("--batch", type=int, default=1)
+    p.add_argument("--size", type=int, default=512)
+    p.add_argument("--passes", type=int, default=5)
+    p.add_argument("--iters", type=int, default=500)
+    p.add_argument("--hist_mode", type=str, choices=["sym", "pca", "chol", "cdf", "sort"], default="chol")
+    p.add_argument("--color_transfer", type=str, default=None, choices=["lum", "opt"])
+    p.add_argument("--content_strength", type=float, default=0.01)
+    p.add_argument("--style_scale", type=float, default=1.0)
+    p.add_argument("--mixing_alpha", type=float, default=0.5)
+    p.add_argument("--no_pca", action="store_true")
+    p.add_argument("--no_multires", action="store_true")
+    p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--no_tf32", action="store_true", help="accepted for compatibility: gfx950 has no TF32, fp32 is exact")
+    p.add_argument("--cudnn_benchmark", action="store_true", help="MIOpen find mode")
+    p.add_argument("--compile", action="store_true", help="accepted for compatibility, ignored (no tracing compiler)")
+    p.add_argument("--script", action="store_true", help="accepted for compatibility, ignored")
+    p.add_argument("--device", type=str, default=None, help="accepted for compatibility (the reference ignores it too)")
+    p.add_argument("--memory_format", type=str, default="contiguous", choices=["contiguous", "channels_last"])
+    p.add_argument("--output_dir", type=str, default="output/")
+    # extensions
+    p.add_argument("--layers", type=int, nargs="+", default=[5, 4, 3, 2, 1], help="VGG depths to run (reluN_1)")
+    p.add_argument("--models_dir", type=str, default="models", help="directory with the pretrained .pth files")
+    p.add_argument("--independent", action="store_true", help="--batch images are independent textures (not pooled)")
+    p.add_argument("--np_seed", type=int, default=None, help="seed numpy's global RNG (drives the rotations)")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    torch.backends.cudnn.benchmark = args.cudnn_benchmark
+    memory_format = torch.contiguous_format if args.memory_format == "contiguous" else torch.channels_last
+    rank, world, device = otdist.init_distributed()
+    if device.type != "cuda":
+        raise SystemExit("optex.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.seed is not None:
+        torch.manual_seed(args.seed + rank)
+    if args.np_seed is not None:
+        np.random.seed(args.np_seed)
+
+    with torch.inference_mode():
+        styles = load_styles(args.style, size=args.size, scale=args.style_scale, device=device, memory_format=memory_format)
+        if len(styles) > 1:
+            assert styles[0].shape == styles[1].shape, "Style images must have the same shape"
+        content = maybe_load_content(args.content, size=args.size, device=device, memory_format=memory_format)
+        lo, hi = otdist.shard_range(args.batch, rank, world) if (world > 1 and args.independent) else (0, args.batch)
+        shape = content.shape if content is not None else (hi - lo, 3, args.size, args.size)
+        pastiche = torch.rand(shape).to(device=device, memory_format=memory_format)
+
+        texturizer = OptimalTexture(
+            size=args.size, iters=args.iters, passes=args.passes, hist_mode=args.hist_mode,
+            color_transfer=args.color_transfer, content_strength=args.content_strength, style_scale=args.style_scale,
+            mixing_alpha=args.mixing_alpha, no_pca=args.no_pca, no_multires=args.no_multires, layers=args.layers,
+            models_dir=args.models_dir, independent=args.independent).to(device)
+        if world > 1:
+            texturizer.style_sync = otdist.StyleSync(device)
+
+        t = time()
+        pastiche = texturizer.forward(pastiche, styles, content, verbose=rank == 0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print("Took:", time() - t)
+    if world > 1:
+        args.output_dir = f"{args.output_dir.rstrip('/')}/rank{rank}"
+    print("\n".join(save_image(pastiche, args)))
+
+
+if __name__ == "__main__":
+    main()

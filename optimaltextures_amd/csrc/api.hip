@@ -1,4 +1,7 @@
 // api.hip — error plumbing and device queries for the C ABI in include/optex.h
+#include <mutex>
+#include <vector>
+
 #include "optex_common.h"
 
 namespace optex {
@@ -33,7 +36,90 @@ int device_cu_count() {
     return cached_cu;
 }
 
+// ---------------------------------------------------------------------------------------------- profiler
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    struct Rec { int cls; hipEvent_t e0, e1; };
+    std::vector<Rec> recs;
+    double flops[KC_COUNT] = {0}, bytes[KC_COUNT] = {0};
+    long long launches[KC_COUNT] = {0};
+    std::mutex mu;
+};
+static ProfState g_prof;
+
+static hipEvent_t prof_event() {
+    if (!g_prof.pool.empty()) {
+        hipEvent_t e = g_prof.pool.back();
+        g_prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(int c, hipStream_t s, double flops, double bytes) : cls(c), st(s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    e0 = prof_event();
+    e1 = prof_event();
+    g_prof.flops[cls] += flops;
+    g_prof.bytes[cls] += bytes;
+    g_prof.launches[cls] += 1;
+    if (e0) (void)hipEventRecord(e0, st);
+}
+
+ProfScope::~ProfScope() {
+    if (!e0 || !e1) return;
+    (void)hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.recs.push_back({cls, e0, e1});
+}
+
+static const char* kClassNames[KC_COUNT] = {"gemm_tn", "col_minmax", "col_hist", "cdf_lut", "cdf_apply", "sort_columns",
+                                            "sort_match", "col_mean", "gram", "cov_finalize", "householder", "interp"};
+
 }  // namespace optex
+
+extern "C" int optex_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(optex::g_prof.mu);
+    optex::g_prof.on = on != 0;
+    return OPTEX_OK;
+}
+
+extern "C" int optex_prof_num_classes(void) { return optex::KC_COUNT; }
+
+extern "C" const char* optex_prof_class_name(int cls) {
+    return (cls >= 0 && cls < optex::KC_COUNT) ? optex::kClassNames[cls] : "?";
+}
+
+// Waits for the recorded events (this is the one call of the library that blocks), sums the elapsed time per class
+// into ms[], copies launch counts and algorithmic flops / bytes, then resets the counters.
+extern "C" int optex_prof_collect(int n, double* ms, long long* launches, double* flops, double* bytes) {
+    using namespace optex;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (int i = 0; i < n && i < KC_COUNT; i++) {
+        if (ms) ms[i] = 0.0;
+        if (launches) launches[i] = g_prof.launches[i];
+        if (flops) flops[i] = g_prof.flops[i];
+        if (bytes) bytes[i] = g_prof.bytes[i];
+    }
+    for (auto& r : g_prof.recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess && ms &&
+            r.cls < n)
+            ms[r.cls] += (double)t;
+        g_prof.pool.push_back(r.e0);
+        g_prof.pool.push_back(r.e1);
+    }
+    g_prof.recs.clear();
+    for (int i = 0; i < KC_COUNT; i++) {
+        g_prof.launches[i] = 0;
+        g_prof.flops[i] = g_prof.bytes[i] = 0.0;
+    }
+    return OPTEX_OK;
+}
 
 extern "C" int optex_abi_version(void) { return OPTEX_ABI_VERSION; }
 

@@ -336,6 +336,7 @@ static int launch_minmax(const float* x, long ld, long ss, long n, int C, int n_
     const int vec = aligned16(x) && ld % 4 == 0 && ss % 4 == 0;
     long chunk = pick_chunk(n, ncols, device_cu_count());
     const int chunks = (int)((n + chunk - 1) / chunk);
+    ProfScope prof(KC_MINMAX, st, 0.0, 4.0 * (double)n * ncols);
     if (chunks <= 1) {
         hipLaunchKernelGGL(col_minmax_kernel<false>, dim3(ncols, 1), dim3(256), 0, st, x, ld, ss, n, C, n, omn, omx,
                            o_n_seg, mn, mx, vec);
@@ -361,6 +362,7 @@ static int launch_hist(const float* x, long ld, long ss, long n, int C, int x_n_
             return OPTEX_E_LAUNCH;
         }
     }
+    ProfScope prof(KC_HIST, st, 0.0, 4.0 * (double)n * ncols);
     hipLaunchKernelGGL(col_hist_kernel, dim3(ncols, chunks < 1 ? 1 : chunks), dim3(256), 0, st, x, ld, ss, n, C,
                        x_n_seg, chunk, lo, hi, hist, vec);
     return check_launch("col_hist_kernel");
@@ -402,11 +404,15 @@ int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float
     if ((rc = launch_hist(target, ldt, tss, nt, C, n_seg, n_seg, w.lo, w.hi, w.ht, st))) return rc;
     if ((rc = launch_hist(source, lds, sss, ns, C, src_n_seg, n_seg, w.lo, w.hi, w.hs, st))) return rc;
     const int ncols = C * n_seg;
-    hipLaunchKernelGGL(cdf_lut_kernel, dim3(ncols), dim3(256), 0, st, w.ht, w.hs, w.lo, w.hi, w.lut, dbg);
+    {
+        ProfScope prof(KC_LUT, st, 0.0, (2.0 * 4 + 3.0 * 4) * kBins * ncols);
+        hipLaunchKernelGGL(cdf_lut_kernel, dim3(ncols), dim3(256), 0, st, w.ht, w.hs, w.lo, w.hi, w.lut, dbg);
+    }
     if ((rc = check_launch("cdf_lut_kernel"))) return rc;
     const int vec = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0 && aligned16(out) && ldo % 4 == 0 && oss % 4 == 0;
     long chunk = pick_chunk(nt, ncols, device_cu_count());
     const int chunks = (int)((nt + chunk - 1) / chunk);
+    ProfScope prof(KC_APPLY, st, 0.0, 8.0 * (double)nt * ncols);
     hipLaunchKernelGGL(cdf_apply_kernel, dim3(ncols, chunks < 1 ? 1 : chunks), dim3(256), 0, st, target, ldt, tss, nt, C,
                        chunk, w.lo, w.hi, w.lut, out, ldo, oss, vec);
     return check_launch("cdf_apply_kernel");
@@ -441,6 +447,7 @@ extern "C" int optex_interp(const float* x, long nx, const float* xp, const floa
         return OPTEX_E_ARG;
     }
     if (nx == 0) return OPTEX_OK;
+    ProfScope prof(KC_INTERP, as_stream(stream), 0.0, 8.0 * (double)nx);
     hipLaunchKernelGGL(interp_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, as_stream(stream), x, nx, xp,
                        fp, (int)np_, out);
     return check_launch("interp_kernel");

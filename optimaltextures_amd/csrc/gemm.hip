@@ -259,6 +259,8 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
         set_error("optex_gemm_tn: bad grid (%lld tiles)", total);
         return OPTEX_E_ARG;
     }
+    ProfScope prof(KC_GEMM, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
+                   4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
     if (vec)
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BPM, OPM, true>), dim3((unsigned)total), dim3(NT), 0, st, a);
     else

@@ -178,7 +178,10 @@ extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long
     }
     hipStream_t st = as_stream(stream);
     const int vec = aligned16(x) && ld % 4 == 0 && seg_stride % 4 == 0;
-    hipLaunchKernelGGL(col_mean_kernel, dim3(C * n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, vec);
+    {
+        ProfScope prof(KC_MEAN, st, 0.0, 4.0 * (double)n * C * n_seg);
+        hipLaunchKernelGGL(col_mean_kernel, dim3(C * n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, vec);
+    }
     int rc = check_launch("col_mean_kernel");
     if (rc) return rc;
     const int tiles = (C + GT - 1) / GT, pairs = tiles * (tiles + 1) / 2;
@@ -186,10 +189,15 @@ extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long
     long chunk = (n + splits - 1) / splits;
     chunk = (chunk + GK - 1) / GK * GK;  // chunk starts stay multiples of 4 pixels (float4 loads)
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(gram_kernel, dim3(pairs, splits, n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, chunk,
-                       tiles, part, vec);
+    {
+        // upper-triangular tile pairs only: pairs * GT*GT * 2n flop per segment
+        ProfScope prof(KC_GRAM, st, 2.0 * pairs * GT * GT * (double)n * n_seg, 4.0 * (double)n * C * n_seg);
+        hipLaunchKernelGGL(gram_kernel, dim3(pairs, splits, n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, chunk,
+                           tiles, part, vec);
+    }
     if ((rc = check_launch("gram_kernel"))) return rc;
     const float N = pool ? (float)((double)n * n_seg) : (float)n;
+    ProfScope prof(KC_COVFIN, st, 0.0, 4.0 * (double)C * C * n_seg * (splits + 1));
     hipLaunchKernelGGL(cov_finalize_kernel, dim3((C + 63) / 64, C, pool ? 1 : n_seg), dim3(64), 0, st, part, C, n_seg,
                        splits, pool, N, eps, cov);
     return check_launch("cov_finalize_kernel");

@@ -54,6 +54,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+// Off by default: no events, no overhead.  Classes are stable ABI (optex_prof_class_name).
+enum KClass { KC_GEMM = 0, KC_MINMAX, KC_HIST, KC_LUT, KC_APPLY, KC_SORT, KC_SORT_MATCH, KC_MEAN, KC_GRAM, KC_COVFIN,
+              KC_ROTGEN, KC_INTERP, KC_COUNT };
+struct ProfScope {
+    int cls;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(int cls, hipStream_t st, double flops, double bytes);
+    ~ProfScope();
+};
+
 // implemented in cdf.hip / sort.hip, shared with the fused loop in ot_loop.hip
 int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,

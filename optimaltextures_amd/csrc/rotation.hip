@@ -104,6 +104,7 @@ extern "C" int optex_rotations_from_normals(const double* normals, int N, int co
     const long per = optex_rotation_normals(N);
     double* V = static_cast<double*>(ws);
     double* D = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up((size_t)count * per * sizeof(double), 256));
+    ProfScope prof(KC_ROTGEN, st, 2.0 * (double)N * N * N * count, 8.0 * (double)per * count + 16.0 * N * N * count);
     hipLaunchKernelGGL(householder_prep_kernel, dim3(N - 1, count), dim3(64), 0, st, normals, N, per, V, D);
     int rc = check_launch("householder_prep_kernel");
     if (rc) return rc;

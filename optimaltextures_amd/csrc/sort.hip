@@ -166,6 +166,10 @@ static int launch_sort_items(const SortArgs& a, int ncols, hipStream_t st) {
         }
         attr_done = true;
     }
+    // algorithmic bytes: read key 4 + write key 4 + write index 4 per element; the match reads the
+    // column (4), reads one source order statistic per pixel (4) and writes the matched column (4)
+    const double per_elem = (MODE == SORT_EMIT) ? (4.0 + (a.out_keys ? 4.0 : 0.0) + (a.out_idx ? 4.0 : 0.0)) : 12.0;
+    ProfScope prof(MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH, st, 0.0, per_elem * (double)a.n * ncols);
     hipLaunchKernelGGL(kern, dim3(ncols), dim3(SORT_NT), lds, st, a);
     return check_launch("sort_columns_kernel");
 }

@@ -1,0 +1,273 @@
+"""Orchestration around the hot path — own counterpart of the reference's OptimalTexture (optex.py:15-139), fit_pca
+(optex.py:180-190) and mix_style_features (optex.py:193-206), restructured for MI355X:
+
+  * features never leave channel-major NCHW memory ([segment][channel][pixel]); the NHWC views the reference shuffles
+    around (vgg.py:153, histmatch.py:6-8,46) do not exist here, so no kernel in the loop transposes;
+  * PCA project / unproject (optex.py:110,120) run on the same MFMA GEMM as the rotations;
+  * all rotations of a (pass, layer) are generated in one batched device launch from one host draw of the numpy stream;
+  * cdf / sort iterations are enqueued by one C call (optex_ot_loop), the linear modes by a short Python loop around
+    torch.linalg's C x C factorizations;
+  * `independent=True` turns a batch into independent textures (one segment each, shared rotations): the reference's
+    --batch pools all images into ONE distribution (histmatch.py:11,17-18), which is kept as the default.
+"""
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+from torch.nn.functional import interpolate
+
+from . import ops, rotation
+from .histmatch import LINEAR_MODES, hist_match, transfer_operator
+from .ops import Seg
+from .util import get_iters_and_sizes, get_size, layer_iters, resize, to_nchw, to_nhwc
+from .vgg import Decoder, Encoder
+
+LOOP_MODES = ("cdf", "sort")
+
+
+# ------------------------------------------------------------------------------------------------ PCA (optex.py:180-190)
+def fit_pca_cm(style_cm: Tensor):
+    """style_cm [B, C, n] -> (projected [B, k, n], eigvecs [C, k]).  Reference quirks kept: centring by the GLOBAL scalar
+    mean, projecting the UNCENTRED tensor, k = first index whose cumulative *singular-value* share exceeds 0.9."""
+    b, c, n = style_cm.shape
+    a = style_cm.permute(0, 2, 1).reshape(-1, c) - style_cm.mean()
+    _, sing, vh = torch.linalg.svd(a, full_matrices=False)
+    share = torch.cumsum(sing / torch.sum(sing), dim=0)
+    k = int((share > 0.9).to(torch.int32).argmax().item())
+    if k < 2:
+        raise ValueError(f"PCA kept {k} component(s); the rotation needs a dimension greater than 1 "
+                         "(the reference fails the same way in special_ortho_group.rvs)")
+    eigvecs = vh[:k].t().contiguous()  # [C, k]
+    return project_cm(style_cm, eigvecs), eigvecs
+
+
+def fit_pca(tensor: Tensor):
+    """reference signature: NHWC features -> (features @ eigvecs, eigvecs)"""
+    b, h, w, c = tensor.shape
+    proj, eigvecs = fit_pca_cm(to_nchw(tensor).reshape(b, c, h * w).contiguous())
+    return proj.view(b, -1, h, w).permute(0, 2, 3, 1), eigvecs
+
+
+def project_cm(x_cm: Tensor, eigvecs: Tensor) -> Tensor:
+    """[S, C, n] -> [S, k, n]  (== x_nhwc @ eigvecs, optex.py:110)"""
+    s, c, n = x_cm.shape
+    k = eigvecs.shape[1]
+    out = torch.empty((s, k, n), dtype=torch.float32, device=x_cm.device)
+    return ops.gemm_tn(eigvecs, x_cm, out, k, c, n, s, lda=k, ldb=n, b_ss=c * n, ldo=n, o_ss=k * n)
+
+
+def unproject_cm(x_cm: Tensor, eigvecs_t: Tensor) -> Tensor:
+    """[S, k, n] -> [S, C, n]  (== x_nhwc @ eigvecs.T, optex.py:120); eigvecs_t = eigvecs.T contiguous [k, C]"""
+    s, k, n = x_cm.shape
+    c = eigvecs_t.shape[1]
+    out = torch.empty((s, c, n), dtype=torch.float32, device=x_cm.device)
+    return ops.gemm_tn(eigvecs_t, x_cm, out, c, k, n, s, lda=c, ldb=n, b_ss=k * n, ldo=n, o_ss=c * n)
+
+
+# ------------------------------------------------------------------------------------------------ style mixing (optex.py:193-206)
+def mix_style_features(style_features: List[Tensor], mixing_mask: Tensor, mixing_alpha: float, hist_mode: str):
+    """NHWC style feature pairs [2,H,W,C] -> one blended target [1,H,W,C] per layer"""
+    i = mixing_alpha
+    for l, sf in enumerate(style_features):
+        mix = to_nhwc(interpolate(mixing_mask, size=sf.shape[1:3], mode="nearest"))
+        a, b = sf[[0]], sf[[1]]
+        a_to_b = hist_match(a, b, mode=hist_mode)
+        b_to_a = hist_match(b, a, mode=hist_mode)
+        style_features[l] = (a * (1 - i) + a_to_b * i) * mix + (b_to_a * (1 - i) + b * i) * (1 - mix)
+    return style_features
+
+
+# ------------------------------------------------------------------------------------------------ colour helpers (kornia absent)
+def rgb_to_hls(img: Tensor) -> Tensor:
+    r, g, b = img[:, 0], img[:, 1], img[:, 2]
+    mx, mn = img.max(1).values, img.min(1).values
+    l = (mx + mn) / 2
+    d = mx - mn
+    s = torch.where(l < 0.5, d / (mx + mn).clamp_min(1e-12), d / (2 - mx - mn).clamp_min(1e-12))
+    s = torch.where(d == 0, torch.zeros_like(s), s)
+    dz = torch.where(d == 0, torch.ones_like(d), d)
+    h = torch.where(mx == r, ((g - b) / dz) % 6, torch.where(mx == g, (b - r) / dz + 2, (r - g) / dz + 4))
+    h = torch.where(d == 0, torch.zeros_like(h), h) * (torch.pi / 3)
+    return torch.stack([h, l, s], 1)
+
+
+def hls_to_rgb(img: Tensor) -> Tensor:
+    h, l, s = img[:, 0] * (6 / (2 * torch.pi)), img[:, 1], img[:, 2]
+    a = s * torch.minimum(l, 1 - l)
+
+    def f(n):
+        k = (n + h * 2) % 12
+        return l - a * torch.clamp(torch.minimum(k - 3, 9 - k), -1, 1)
+
+    return torch.stack([f(0), f(8), f(4)], 1)
+
+
+# ------------------------------------------------------------------------------------------------ the hot loop
+def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content: Optional[Tensor] = None,
+                  strength: float = 0.0, pooled: bool = False, rng=None) -> Tensor:
+    """`iters` sliced-OT steps (optex.py:112-117) on channel-major segments.  x [S, C, n] is updated in place and
+    returned; style [1 or S, C, ns]; content None or [S, C, n].  pooled=True reproduces the reference's batch
+    semantics (all S images form ONE distribution per channel); otherwise segments are independent textures."""
+    s, c, n = x.shape
+    if iters <= 0:
+        return x
+    R32, Rt32 = rotation.rotations(c, iters, x.device, rng=rng)
+    if content is not None and content.shape[0] != s:
+        content = content.expand(s, c, n).contiguous()
+    if pooled and s > 1:
+        return _pooled_iterations(x, style, hist_mode, R32, Rt32, content, strength)
+    if hist_mode in LOOP_MODES:
+        return ops.ot_loop(hist_mode, x, style, R32, Rt32, content=content, strength=strength)
+    if hist_mode not in LINEAR_MODES:
+        raise ValueError(f"hist_mode must be one of chol|pca|sym|cdf|sort, got {hist_mode!r}")
+    ss = style.shape[0]
+    y, ys, m = torch.empty_like(x), torch.empty_like(style), torch.empty_like(x)
+    for it in range(iters):
+        ops.rotate_seg(x, R32[it], out=y)           # optex.py:170
+        ops.rotate_seg(style, R32[it], out=ys)      # optex.py:171
+        mu_t, cov_t = ops.linear_stats(Seg.of(y), pool=False)    # histmatch.py:16-18
+        mu_s, cov_s = ops.linear_stats(Seg.of(ys), pool=False)   # histmatch.py:20-22
+        tt = transfer_operator(cov_t, cov_s, hist_mode).mT.contiguous()  # histmatch.py:24-42
+        ops.gemm_tn(tt, y, m, c, c, n, s, lda=c, at_ss=c * c, ldb=n, b_ss=c * n, ldo=n, o_ss=c * n, bsub=mu_t, bsub_ss=c,
+                    badd=mu_s, badd_ss=c if ss == s else 0)          # histmatch.py:27/34/42,44
+        ops.unrotate_seg(m, Rt32[it], out=x, content=content, strength=strength)  # optex.py:175 + 115-117
+    return x
+
+
+def _pooled_iterations(x, style, hist_mode, R32, Rt32, content, strength):
+    """reference --batch semantics: rotate NCHW segments straight into pooled rows [C, S*n], match, rotate back"""
+    from .histmatch import linear_match_pooled
+    s, c, n = x.shape
+    ss, _, ns = style.shape
+    y = torch.empty((c, s * n), dtype=torch.float32, device=x.device)
+    ys = torch.empty((c, ss * ns), dtype=torch.float32, device=x.device)
+    for it in range(R32.shape[0]):
+        ops.gemm_tn(R32[it], x, y, c, c, n, s, lda=c, ldb=n, b_ss=c * n, ldo=s * n, o_ss=n)
+        ops.gemm_tn(R32[it], style, ys, c, c, ns, ss, lda=c, ldb=ns, b_ss=c * ns, ldo=ss * ns, o_ss=ns)
+        if hist_mode == "cdf":
+            m = ops.cdf_match_seg(Seg.of(y[None]), Seg.of(ys[None]), out=Seg.of(y[None]))[0]
+        elif hist_mode == "sort":
+            m = ops.sort_match_seg(Seg.of(y[None]), Seg.of(ys[None]), out=Seg.of(y[None]))[0]
+        else:
+            m = linear_match_pooled(y, s, ys, ss, hist_mode)
+        ops.gemm_tn(Rt32[it], m, x, c, c, n, s, lda=c, ldb=s * n, b_ss=n, ldo=n, o_ss=c * n, content=content,
+                    strength=strength)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ OptimalTexture
+class OptimalTexture(torch.nn.Module):
+    """Same constructor arguments and defaults as the reference (optex.py:16-28) plus extensions:
+    layers (VGG depths to run, deepest first; the reference hard-codes 5..1), models_dir (pretrained weights),
+    independent (batch = independent textures instead of one pooled distribution)."""
+
+    def __init__(self, size: int = 512, iters: int = 500, passes: int = 5, hist_mode: str = "chol",
+                 color_transfer: Optional[str] = None, content_strength: float = 0.1, style_scale: float = 1,
+                 mixing_alpha: float = 0.5, no_pca: bool = False, no_multires: bool = False,
+                 layers=(5, 4, 3, 2, 1), models_dir: Optional[str] = None, independent: bool = False):
+        super().__init__()
+        self.hist_mode = hist_mode
+        self.color_transfer = color_transfer
+        self.content_strength = content_strength
+        self.style_scale = style_scale
+        self.mixing_alpha = mixing_alpha
+        self.use_pca = not no_pca
+        self.independent = independent
+        self.passes = passes
+        self.iters_per_pass_and_layer, self.sizes = get_iters_and_sizes(size, iters, passes, not no_multires)
+        self.layers = tuple(sorted({int(l) for l in layers}, reverse=True))
+        self.encoders = torch.nn.ModuleList([Encoder(l, models_dir) for l in self.layers])
+        self.decoders = torch.nn.ModuleList([Decoder(l, models_dir) for l in self.layers])
+        self.style_sync = None  # multi-GPU hook: callable(list of tensors or None) -> list of tensors (dist.py)
+        self.rng = None         # numpy RandomState for the rotations (None = numpy's global state, like the reference)
+
+    # -- optex.py:45-79, channel-major
+    def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int):
+        if pastiche.shape[-2] != size and pastiche.shape[-1] != size:
+            style_tens = [resize(s, size=get_size(size, self.style_scale, s.shape[2], s.shape[3])) for s in styles]
+            if content is not None:
+                cont_size = get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True)
+                cont_tens = resize(content, size=cont_size)
+            else:
+                cont_size, cont_tens = (size, size), None
+            pastiche = resize(pastiche, size=cont_size)
+        else:
+            style_tens, cont_tens = styles, content
+
+        style_features, style_eigvs, content_features, style_hw = [], [], [], []
+        for encoder in self.encoders:
+            payload = None
+            if self.style_sync is None or self.style_sync.is_source:
+                sf = torch.cat([encoder.features(s) for s in style_tens])  # [n_styles, C, Hs, Ws]
+                hw = sf.shape[2:]
+                sf = sf.reshape(sf.shape[0], sf.shape[1], -1)
+                if self.use_pca:
+                    sf, eigvecs = fit_pca_cm(sf)
+                else:
+                    eigvecs = torch.empty((0, 0), device=sf.device)
+                payload = [sf.contiguous(), eigvecs, torch.tensor(list(hw), device=sf.device, dtype=torch.float32)]
+            if self.style_sync is not None:
+                payload = self.style_sync(payload)
+            sf, eigvecs, hw = payload
+            style_features.append(sf)
+            style_eigvs.append(eigvecs)
+            style_hw.append((int(hw[0].item()), int(hw[1].item())))
+            if cont_tens is not None:
+                cf = encoder.features(cont_tens)
+                cf = cf.reshape(cf.shape[0], cf.shape[1], -1)
+                if self.use_pca:
+                    cf = project_cm(cf.contiguous(), eigvecs)
+                cf = cf - cf.mean() + torch.mean(sf)  # scalar re-centring (optex.py:76)
+                content_features.append(cf.contiguous())
+        return pastiche, style_features, style_eigvs, content_features, style_hw
+
+    def forward(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor] = None, verbose: bool = False):
+        for p in range(self.passes):
+            if verbose:
+                print(f"Pass {p}, size {self.sizes[p]}")
+            pastiche, style_features, style_eigvs, content_features, style_hw = self.encode_inputs(
+                pastiche, styles, content, self.sizes[p])
+
+            if len(styles) > 1:
+                # the reference sizes the mask on the relu4_1 grid (style_features[1], optex.py:98-99)
+                ref = min(1, len(style_hw) - 1)
+                mask = torch.ceil(torch.rand(style_hw[ref], device=pastiche.device) - self.mixing_alpha)[None, None]
+                nhwc = [sf.view(sf.shape[0], sf.shape[1], *hw).permute(0, 2, 3, 1) for sf, hw in zip(style_features, style_hw)]
+                mixed = mix_style_features(nhwc, mask, self.mixing_alpha, self.hist_mode)
+                style_features = [to_nchw(m).reshape(1, m.shape[-1], -1).contiguous() for m in mixed]
+
+            for li, (encoder, decoder) in enumerate(zip(self.encoders, self.decoders)):
+                enc_index = 5 - encoder.depth  # position in the reference's encoder list (0 = relu5_1)
+                if verbose:
+                    print(f"Layer: relu{encoder.depth}_1")
+                feat = encoder.features(pastiche)
+                b, c, h, w = feat.shape
+                x = feat.reshape(b, c, h * w)
+                if self.use_pca:
+                    x = project_cm(x.contiguous(), style_eigvs[li])
+                elif not x.is_contiguous():
+                    x = x.contiguous()
+                blend = len(content_features) > 0 and enc_index <= 2
+                strength = self.content_strength / 2 ** (4 - enc_index) if blend else 0.0
+                x = ot_iterations(x, style_features[li], self.hist_mode,
+                                  layer_iters(self.iters_per_pass_and_layer, p, enc_index),
+                                  content=content_features[li] if blend else None, strength=strength,
+                                  pooled=not self.independent, rng=self.rng)
+                if self.use_pca:
+                    x = unproject_cm(x, style_eigvs[li].t().contiguous())
+                pastiche = decoder.decode(x.view(b, -1, h, w))
+
+        if self.color_transfer is not None:
+            assert content is not None, "Color transfer requires content image"
+            target_hls = rgb_to_hls(content)
+            target_hls[:, 1] = rgb_to_hls(pastiche)[:, 1]  # swap lightness channel
+            target = hls_to_rgb(target_hls)
+            if self.color_transfer == "opt":
+                b, _, h, w = pastiche.shape
+                x = pastiche.reshape(b, 3, h * w).contiguous()
+                t = target.reshape(target.shape[0], 3, -1).contiguous()
+                x = ot_iterations(x, t, "cdf", 3, pooled=not self.independent, rng=self.rng)
+                pastiche = x.view(b, 3, h, w)
+            elif self.color_transfer == "lum":
+                pastiche = target
+        return pastiche

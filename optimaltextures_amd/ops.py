@@ -177,3 +177,18 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0):
     check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), iters,
                             ptr(content), ctypes.c_float(strength), ptr(ws), stream_ptr()))
     return x
+
+
+def profile_enable(on=True):
+    check(_lib.lib().optex_prof_enable(int(bool(on))))
+
+
+def profile_collect():
+    """{class name: dict(ms, launches, flops, bytes)} measured with HIP events on the launch stream; resets the tallies"""
+    lib = _lib.lib()
+    k = lib.optex_prof_num_classes()
+    ms, fl, by = (ctypes.c_double * k)(), (ctypes.c_double * k)(), (ctypes.c_double * k)()
+    ln = (ctypes.c_longlong * k)()
+    check(lib.optex_prof_collect(k, ms, ln, fl, by))
+    return {lib.optex_prof_class_name(i).decode(): dict(ms=ms[i], launches=int(ln[i]), flops=fl[i], bytes=by[i])
+            for i in range(k) if ln[i]}

@@ -1,0 +1,97 @@
+"""Truncated normalised VGG-19 encoders and their learned inverters (reference vgg.py:14-171).  These stay on
+PyTorch-ROCm (MIOpen) by the north-star's scoping; only the interface is kept: Encoder(depth) maps NCHW images to
+features, Decoder(depth) maps features back.  Module order inside the nn.Sequential matches the reference so that its
+state_dicts (`models/vgg_normalised_conv{d}_1.pth`, `models/feature_invertor_conv{d}_1.pth`, keys "2.weight" ...) load
+unchanged from `models_dir`.  Without a models_dir (the GPU box has no assets) weights are seeded synthetic
+(variance-preserving init), which leaves shapes, FLOPs and therefore throughput identical."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .util import to_nchw, to_nhwc
+
+WIDTHS = (64, 128, 256, 512, 512)
+# number of extra 3x3 convs at the block's own width before the pool that leads to the NEXT block
+_SAME_WIDTH_CONVS = (1, 1, 3, 3)
+
+
+def _conv(cin, cout):
+    return [nn.ReflectionPad2d((1, 1, 1, 1)), nn.Conv2d(cin, cout, (3, 3)), nn.ReLU()]
+
+
+def encoder_layers(depth: int):
+    mods = [nn.Conv2d(3, 3, (1, 1))] + _conv(3, WIDTHS[0])
+    for d in range(1, depth):
+        w = WIDTHS[d - 1]
+        for _ in range(_SAME_WIDTH_CONVS[d - 1]):
+            mods += _conv(w, w)
+        mods.append(nn.MaxPool2d((2, 2), (2, 2), (0, 0), ceil_mode=True))
+        mods += _conv(w, WIDTHS[d])
+    return mods
+
+
+def decoder_layers(depth: int):
+    mods = []
+    for d in range(depth, 1, -1):
+        w = WIDTHS[d - 2]
+        mods += _conv(WIDTHS[d - 1], w)
+        mods.append(nn.UpsamplingNearest2d(scale_factor=2))
+        for _ in range(_SAME_WIDTH_CONVS[d - 2]):
+            mods += _conv(w, w)
+    mods += [nn.ReflectionPad2d((1, 1, 1, 1)), nn.Conv2d(WIDTHS[0], 3, (3, 3))]
+    return mods
+
+
+def _synthetic_init(model: nn.Sequential, seed: int):
+    gen = torch.Generator().manual_seed(seed)
+    for m in model:
+        if isinstance(m, nn.Conv2d):
+            fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+            with torch.no_grad():
+                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * (2.0 / fan_in) ** 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.05)
+
+
+class _Codec(nn.Module):
+    FILE = ""
+
+    def __init__(self, depth: int, layers, models_dir=None, seed=0):
+        super().__init__()
+        assert isinstance(depth, int) and 1 <= depth <= 5
+        self.depth = depth
+        self.model = nn.Sequential(*layers)
+        path = os.path.join(models_dir, self.FILE.format(depth)) if models_dir else None
+        if path and os.path.exists(path):
+            self.model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+            self.weights = "pretrained:" + path
+        else:
+            _synthetic_init(self.model, seed + depth)
+            self.weights = "synthetic(seed=%d)" % (seed + depth)
+
+
+class Encoder(_Codec):
+    FILE = "vgg_normalised_conv{}_1.pth"
+
+    def __init__(self, depth: int, models_dir=None):
+        super().__init__(depth, encoder_layers(depth), models_dir, seed=100)
+
+    def features(self, x):
+        """NCHW image -> NCHW feature (channel-major per image: the layout every OT kernel wants)"""
+        return self.model(x)
+
+    def forward(self, x):
+        return to_nhwc(self.model(x))  # the reference's contract: an NHWC view of NCHW memory (vgg.py:153)
+
+
+class Decoder(_Codec):
+    FILE = "feature_invertor_conv{}_1.pth"
+
+    def __init__(self, depth: int, models_dir=None):
+        super().__init__(depth, decoder_layers(depth), models_dir, seed=200)
+
+    def decode(self, feat_nchw):
+        return self.model(feat_nchw)
+
+    def forward(self, x):
+        return self.model(to_nchw(x))

@@ -143,6 +143,7 @@ void orc_random_rotation(double* normals, int N, double* H) {
     double* D = (double*)malloc(sizeof(double) * (size_t)N);
     for (int i = 0; i < N; i++)
         for (int j = 0; j < N; j++) H[(size_t)i * N + j] = (i == j) ? 1.0 : 0.0;
+    /* phase 1 (sequential, O(N^2)): normalise every Householder vector in place */
     double* x = normals;
     for (int n = 0; n < N - 1; n++) {
         const int len = N - n;
@@ -153,14 +154,20 @@ void orc_random_rotation(double* normals, int N, double* H) {
         x[0] += D[n] * sqrt(norm2);
         const double den = sqrt((norm2 - x0 * x0 + x[0] * x[0]) / 2.);
         for (int j = 0; j < len; j++) x[j] /= den;
+        x += len;
+    }
+    /* phase 2 (O(N^3)): the reflections act on each row of H independently, in order n = 0..N-2 */
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < N; i++) {
+    for (int i = 0; i < N; i++) {
+        const double* v = normals;
+        for (int n = 0; n < N - 1; n++) {
+            const int len = N - n;
             double* h = H + (size_t)i * N + n;
             double s = 0.0;
-            for (int j = 0; j < len; j++) s += h[j] * x[j];
-            for (int j = 0; j < len; j++) h[j] -= s * x[j];
+            for (int j = 0; j < len; j++) s += h[j] * v[j];
+            for (int j = 0; j < len; j++) h[j] -= s * v[j];
+            v += len;
         }
-        x += len;
     }
     double prod = 1.0;
     for (int i = 0; i < N - 1; i++) prod *= D[i];
