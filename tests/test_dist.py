@@ -1,0 +1,120 @@
+"""Multi-process checks of the N > 1 path on CPU (gloo, world_size 2): the texture sharding and the one collective the
+hot path has — the per-(pass, layer) broadcast of style-side data (optimaltextures_amd/dist.py).  On the GPU
+box the same code runs over RCCL ("nccl" backend); nothing here needs a GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from optimaltextures_amd import dist as otdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    r, w, device = otdist.init_distributed("gloo")
+    assert (r, w) == (rank, world) and device.type == "cpu"
+    try:
+        ret[rank] = fn(rank, world, device)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def run_world(fn, world=2):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+        return dict(ret)
+
+
+# ------------------------------------------------------------------------------------------------ sharding (no processes)
+@pytest.mark.parametrize("total,world", [(64, 8), (64, 1), (7, 2), (3, 8), (0, 4), (65, 8)])
+def test_shard_range_partitions_textures(total, world):
+    ranges = [otdist.shard_range(total, r, world) for r in range(world)]
+    covered = [i for lo, hi in ranges for i in range(lo, hi)]
+    assert covered == list(range(total))                       # disjoint, ordered, complete
+    sizes = [hi - lo for lo, hi in ranges]
+    assert max(sizes) - min(sizes) <= 1                        # balanced
+    if total == 64 and world == 8:
+        assert sizes == [8] * 8                                # BASELINE config 4: 8 textures per GPU
+
+
+# ------------------------------------------------------------------------------------------------ broadcast of style data
+def _style_sync_job(rank, world, device):
+    sync = otdist.StyleSync(device)
+    g = torch.Generator().manual_seed(123)
+    out = []
+    # two (pass, layer) rounds with different, data-dependent shapes (the PCA rank k changes per pass)
+    for (c, k, ns) in [(16, 5, 96), (32, 11, 40)]:
+        if sync.is_source:
+            payload = [torch.rand(1, k, ns, generator=g), torch.rand(c, k, generator=g), torch.tensor([8.0, 12.0])]
+        else:
+            payload = None
+        got = sync(payload)
+        out.append([t.numpy().copy() for t in got])
+    # no-PCA round: an empty eigvec tensor must survive the trip
+    payload = [torch.rand(1, 8, 24, generator=g), torch.empty(0, 0), torch.tensor([4.0, 6.0])] if sync.is_source else None
+    got = sync(payload)
+    out.append([t.numpy().copy() for t in got])
+    return out, sync.bytes_moved, otdist.all_reduce_max(float(rank + 1), device)
+
+
+def test_style_sync_broadcast_gloo_world2():
+    res = run_world(_style_sync_job, 2)
+    (a, bytes_a, max_a), (b, bytes_b, max_b) = res[0], res[1]
+    assert max_a == max_b == 2.0                               # bench.py's max-over-ranks timing reduction
+    assert bytes_a == bytes_b > 0
+    for ra, rb in zip(a, b):
+        assert len(ra) == len(rb) == 3
+        for ta, tb in zip(ra, rb):
+            assert ta.shape == tb.shape and np.array_equal(ta, tb)
+    assert a[2][1].shape == (0, 0)
+    assert a[0][0].shape == (1, 5, 96) and a[1][1].shape == (32, 11)
+
+
+# ------------------------------------------------------------------------------------------------ sharded job == single job
+def _sharded_textures_job(rank, world, device):
+    """Each rank synthesises its shard of `total` independent textures with the CPU oracle standing in for the HIP
+    kernels (this is a test of the SHARDING logic: seeds, ranges, broadcast), and returns them."""
+    from oracle import oracle as orc
+    total, C, n, ns, iters = 5, 8, 64, 48, 2
+    sync = otdist.StyleSync(device)
+    style = None
+    if sync.is_source:
+        style = [torch.from_numpy(np.maximum(np.random.default_rng(9).standard_normal((1, C, ns)), 0).astype(np.float32))]
+    style = sync(style)[0].numpy()[0]
+    lo, hi = otdist.shard_range(total, rank, world)
+    outs = {}
+    for i in range(lo, hi):
+        x = np.maximum(np.random.default_rng(100 + i).standard_normal((C, n)), 0).astype(np.float32)
+        rng = orc.LegacyRNG(1000 + i)                            # per-texture rotation stream: rank-independent
+        for _ in range(iters):
+            R = orc.random_rotation(C, rng).astype(np.float32)
+            x = orc.unrotate_cm(orc.cdf_match(orc.rotate_cm(x, R), orc.rotate_cm(style, R)), R)
+        outs[i] = x
+    return outs
+
+
+def test_sharded_textures_equal_single_process():
+    two = run_world(_sharded_textures_job, 2)
+    one = run_world(_sharded_textures_job, 1)
+    merged = {**two[0], **two[1]}
+    assert sorted(merged) == sorted(one[0]) == list(range(5))
+    assert sorted(two[0]) == [0, 1, 2] and sorted(two[1]) == [3, 4]
+    for i in range(5):
+        assert np.array_equal(merged[i], one[0][i])              # sharding changes nothing, bit for bit
