@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at the headline shapes (SURVEY 8d "kernel micro-inputs"): every kernel class of
+liboptex_hip.so on [S, 256, n] channel-major segments, timed with the library's own HIP-event profiler.
+
+    python scripts/microbench.py [--S 32] [--n 16384] [--C 256] [--reps 20] [--only gemm,sort,...]
+
+Prints one JSON line per kernel class: achieved TFLOP/s or GB/s (algorithmic work / event time) and the roofline
+fraction.  Used under rocprofv3 (--kernel-trace --stats, or --pmc passes) to produce profiles/*.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from optimaltextures_amd import ops, rotation  # noqa: E402
+from optimaltextures_amd.ops import Seg  # noqa: E402
+
+PEAK_HBM, PEAK_MFMA = 8000.0, 157.3
+MFMA = ("gemm_tn", "gram")
+
+
+def report(tag, prof):
+    for name, r in prof.items():
+        if r["ms"] <= 0:
+            continue
+        if name in MFMA:
+            ach, peak, unit = r["flops"] / (r["ms"] * 1e9), PEAK_MFMA, "TFLOP/s"
+        else:
+            ach, peak, unit = r["bytes"] / (r["ms"] * 1e6), PEAK_HBM, "GB/s"
+        print(json.dumps({"case": tag, "kernel": name, "achieved": round(ach, 2), "unit": unit,
+                          "frac": round(ach / peak, 4), "avg_us": round(1e3 * r["ms"] / r["launches"], 2),
+                          "launches": r["launches"]}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--S", type=int, default=32)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--ns", type=int, default=12288)
+    ap.add_argument("--C", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", type=str, default="gemm,cdf,sort,linear,loop")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    S, C, n, ns = args.S, args.C, args.n, args.ns
+    only = set(args.only.split(","))
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((S, C, n), device=dev, generator=g).clamp_min_(0) * 2  # ReLU-like features
+    style = torch.randn((1, C, ns), device=dev, generator=g).clamp_min_(0) * 1.5
+    R32, Rt32 = rotation.rotations(C, 4, dev, rng=np.random.RandomState(0))
+    y = torch.empty_like(x)
+    tag = f"S{S}_C{C}_n{n}"
+
+    def timed(fn, reps=args.reps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ops.profile_collect()
+        ops.profile_enable(True)
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        ops.profile_enable(False)
+        return ops.profile_collect()
+
+    if "gemm" in only:
+        report(tag + "_rotate", timed(lambda: ops.rotate_seg(x, R32[0], out=y)))
+        report(tag + "_unrotate_blend", timed(lambda: ops.unrotate_seg(y, Rt32[0], out=y.new_empty(y.shape), content=x,
+                                                                       strength=0.05), reps=5))
+    ops.rotate_seg(x, R32[0], out=y)
+    ys = ops.rotate_seg(style, R32[0])
+    if "cdf" in only:
+        out = torch.empty_like(y)
+        report(tag + "_cdf", timed(lambda: ops.cdf_match_seg(Seg.of(y), Seg.of(ys), out=Seg.of(out))))
+    if "sort" in only and n <= 16384:
+        report(tag + "_sort_kv", timed(lambda: ops.sort_columns(y), reps=5))
+        out = torch.empty_like(y)
+        report(tag + "_sort_match", timed(lambda: ops.sort_match_seg(Seg.of(y), Seg.of(ys), out=Seg.of(out)), reps=5))
+        # tie-heavy variant: un-rotated ReLU features (about half the keys are exactly 0)
+        report(tag + "_sort_kv_ties", timed(lambda: ops.sort_columns(x), reps=5))
+    if "linear" in only:
+        report(tag + "_linear", timed(lambda: ops.linear_stats(Seg.of(y), pool=False), reps=5))
+    if "loop" in only:
+        xx = x.clone()
+        report(tag + "_loop_cdf", timed(lambda: ops.ot_loop("cdf", xx, style, R32, Rt32), reps=3, warm=1))
+
+
+if __name__ == "__main__":
+    main()
