@@ -13,33 +13,20 @@
 //
 // Roofline: 2*M*K*n flop against 4*(K + M)*n + 4*K*M bytes; at C = 256 the intensity is 64 flop/B, i.e.
 // MFMA-bound (157 TFLOP/s fp32 matrix peak); below C ~ 80 it turns HBM-bound.
-#include "optex_common.h"
+#include "gemm_args.h"
 
 namespace optex {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-struct GemmArgs {
-    const float* At; long lda, at_ss;
-    const float* B;  long ldb, b_ss;
-    float* O;        long ldo, o_ss;
-    int M, K; long n; int n_seg;
-    const float* bsub; long bsub_ss;
-    const float* badd; long badd_ss;
-    const float* content; float strength;
-    int tiles_m, tiles_n;
-};
-
-constexpr int BK = 16;       // K-chunk staged per LDS buffer: 8 MFMA steps of k = 2
-constexpr int NT = 256;      // 4 waves, arranged 2 (m) x 2 (n)
-
-template <int BM, int BN, bool BPM, bool OPM, bool VEC>
-__global__ __launch_bounds__(NT) void gemm_tn_kernel(GemmArgs a) {
-    constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
+// BK = K-chunk staged per LDS buffer (BK / 2 MFMA steps of k = 2); the block has WGM x WGN waves (m x n)
+template <int BM, int BN, int BK, int WGM, int WGN, bool BPM, bool OPM, bool VEC>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
     constexpr int BSTR = BPM ? (BK + 1) : BN;   // pixel-major B is staged [pixel][k] with an odd stride
     constexpr int NA = BK * BM / 4 / NT, NB = BK * BN / 4 / NT;
-    static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+    static_assert(NA >= 1 && NB >= 1 && NA * NT * 4 == BK * BM && NB * NT * 4 == BK * BN, "tile / thread count mismatch");
+    static_assert(TM >= 1 && TN >= 1 && TM * 32 * WGM == BM && TN * 32 * WGN == BN, "wave tile must be a multiple of 32x32");
 
     __shared__ float As[2][BK * BM];
     __shared__ float Bs[2][BPM ? BN * (BK + 1) : BK * BN];
@@ -57,7 +44,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(GemmArgs a) {
     const float* __restrict__ bsub = a.bsub ? a.bsub + (size_t)seg * a.bsub_ss : nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, h = lane >> 5;
 
     float4 ra[NA], rb[NB];
@@ -250,8 +237,9 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(GemmArgs a) {
     }
 }
 
-template <int BM, int BN, bool BPM, bool OPM>
+template <int BM, int BN, int BK, int WGM, int WGN, bool BPM, bool OPM>
 static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
+    constexpr int NT = 64 * WGM * WGN;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (int)((a.n + BN - 1) / BN);
     const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
@@ -262,18 +250,28 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
     ProfScope prof(KC_GEMM, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                    4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
     if (vec)
-        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BPM, OPM, true>), dim3((unsigned)total), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WGM, WGN, BPM, OPM, true>), dim3((unsigned)total), dim3(NT), 0, st, a);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BPM, OPM, false>), dim3((unsigned)total), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WGM, WGN, BPM, OPM, false>), dim3((unsigned)total), dim3(NT), 0, st, a);
     return check_launch("gemm_tn_kernel");
 }
 
+// Tile choice (measured on MI355X at the hot-loop shape M = K = 256, n = 32 x 16384, 600 back-to-back launches):
+//   256x128 tile / 512 threads  113 TFLOP/s   <- whole M in one block: the feature map is read from HBM exactly once
+//   128x128 tile / 256 threads  109 TFLOP/s      (every pixel tile is fetched by two m-tiles)
+// Software-pipelined LDS fragment reads, LDS refill under the MFMAs, BK = 8 / 32, and an LDS-free variant streaming
+// fragments straight from L1/L2 were all tried and measured 72-99 TFLOP/s: at 70 % MFMA utilisation the chip already
+// draws 1350 W of its 1400 W cap (rocm-smi), so the kernel is power-limited, not issue-limited.
 template <bool BPM, bool OPM>
 static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
-    // 128x128 tiles read B once per two m-tiles; fall back to 64x64 when that grid would leave CUs idle.
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
-    if (big >= 2LL * n_cu && a.M > 64) return launch_cfg<128, 128, BPM, OPM>(a, vec, st);
-    return launch_cfg<64, 64, BPM, OPM>(a, vec, st);
+    if (big >= 2LL * n_cu && a.M > 64) {
+        const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
+        if (a.M > 128 && huge >= 2LL * n_cu) return launch_cfg<256, 128, 16, 4, 2, BPM, OPM>(a, vec, st);
+        return launch_cfg<128, 128, 16, 2, 2, BPM, OPM>(a, vec, st);
+    }
+    // small problems: 64x64 tiles keep every CU busy
+    return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);
 }
 
 int device_cu_count();

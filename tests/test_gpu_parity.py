@@ -218,6 +218,73 @@ def test_sort_match_vs_oracle_bit_exact(dev, S, Ss, C, nt, ns):
         assert biteq(out[k], orc.sort_match(t[k], s[k if Ss > 1 else 0]))
 
 
+def _sort_edge_columns(n, rng):
+    """columns that exercise every path of the rank kernel and its radix sweep"""
+    cols = {
+        "gaussian": rng.standard_normal(n),
+        "relu_half_zeros": np.maximum(rng.standard_normal(n), 0),                    # one oversized all-equal bucket
+        "constant": np.full(n, 3.25),                                                # klo == khi shortcut
+        "two_values": rng.integers(0, 2, n).astype(np.float64),                      # two oversized all-equal buckets
+        "quantised_256": rng.integers(0, 256, n) / 255.0,                            # many big tie groups -> radix sweep
+        "outlier": np.concatenate([rng.standard_normal(n - 1) * 1e-3, [1e6]]),       # equalisation must absorb it
+        "heavy_tail": rng.standard_cauchy(n),
+        "signed_zeros": np.where(rng.random(n) < 0.5, -0.0, 0.0),                    # totalOrder: -0 < +0, zero range
+        "with_inf_nan": np.concatenate([rng.standard_normal(n - 3), [np.inf, -np.inf, np.nan]]),
+        "ascending": np.arange(n, dtype=np.float64),
+        "descending": -np.arange(n, dtype=np.float64),
+        "tiny_range": 1.0 + rng.integers(0, 3, n) * np.float64(np.finfo(np.float32).eps),
+        "denormals": rng.standard_normal(n) * 1e-41,
+    }
+    names = list(cols)
+    return names, np.stack([cols[k] for k in names]).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [600, 2048, 5000, 16384])
+def test_sort_edge_distributions_indices_bit_exact(dev, n):
+    from optimaltextures_amd import ops
+    names, x = _sort_edge_columns(n, np.random.default_rng(n + 1))
+    keys, idx = ops.sort_columns(cu(x[None], dev))
+    keys, idx = keys.cpu().numpy()[0], idx.cpu().numpy().view(np.uint32)[0]
+    ok, oi = orc.sort_columns(x)
+    for c, name in enumerate(names):
+        assert biteq(idx[c], oi[c]), f"{name}: indices differ"
+        assert biteq(keys[c].view(np.uint32), ok[c].view(np.uint32)), f"{name}: keys differ"
+
+
+@pytest.mark.parametrize("nt,ns", [(2048, 2048), (5000, 3100), (16384, 12288), (12544, 16384)])
+def test_sort_match_edge_distributions_bit_exact(dev, nt, ns):
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    rng = np.random.default_rng(nt + 7 * ns)
+    names, t = _sort_edge_columns(nt, rng)
+    keep = [i for i, k in enumerate(names) if k != "with_inf_nan"]  # nan in the target has no defined match value order
+    t = t[keep]
+    s = (rng.standard_normal((1, len(keep), ns)) * 2 + 1).astype(np.float32)
+    s[0, 1] = np.maximum(s[0, 1], 0)
+    out = ops.sort_match_seg(Seg.of(cu(t[None], dev)), Seg.of(cu(s, dev))).cpu().numpy()[0]
+    want = orc.sort_match(t, s[0])
+    for c, i in enumerate(keep):
+        assert biteq(out[c], want[c]), names[i]
+
+
+def test_sort_full_size_properties(dev):
+    """BASELINE size ([32, 256, 16384]): permutation / sortedness / stability, and the oracle on a column sample"""
+    from optimaltextures_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((32, 256, 16384), device=dev, generator=g)
+    x[:, ::7].clamp_min_(0)  # tie-heavy columns in between
+    keys, idx = ops.sort_columns(x)
+    assert bool((keys[..., 1:] >= keys[..., :-1]).all()), "sorted"
+    idx = idx.long()
+    assert bool((torch.gather(x, 2, idx) == keys).all()), "keys are the gathered input"
+    assert bool((idx.sort(dim=2).values == torch.arange(16384, device=dev)).all()), "indices are a permutation"
+    ties = keys[..., 1:] == keys[..., :-1]
+    assert bool((idx[..., 1:][ties] > idx[..., :-1][ties]).all()), "stable: ties keep pixel order"
+    xs = x[3, 5:9].cpu().numpy()
+    ok, oi = orc.sort_columns(xs)
+    assert biteq(idx[3, 5:9].cpu().numpy().astype(np.uint32), oi)
+
+
 def test_sort_too_long_column_is_a_clean_error(dev):
     from optimaltextures_amd import ops
     with pytest.raises(RuntimeError, match="not supported"):
