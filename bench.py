@@ -200,7 +200,9 @@ def main():
                 by_mode[mode] = round(B / (time.perf_counter() - t0), 3)
         result["textures_per_s_by_hist_mode"] = by_mode
         if not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            # more threads than ~32 only add oversubscription to torch-CPU convs and the OpenMP oracle (measured on the
+            # 256-core GPU host: 256 threads were 5x slower than 8); `cores` reports what was actually used
+            threads = min(os.cpu_count() or 1, 32)
             result["cpu_baseline"] = cpu_baseline(args.hist_mode, threads)
     if rank == 0:
         print(json.dumps(result))

@@ -139,6 +139,17 @@ int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, lon
                   void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * N3  element-wise glue between the VGG convolutions, vgg.py:14-135: conv bias add, nn.ReLU,
+ * nn.MaxPool2d(2, 2, ceil_mode=True) (vgg.py:26 ...), nn.UpsamplingNearest2d(2) (vgg.py:82 ...) and the
+ * nn.ReflectionPad2d(1) in front of every 3x3 convolution, applied in that order in ONE pass:
+ *   out[N, C, Ho, Wo] = pad(up(pool(relu(x[N, C, H, W] + bias[C]))))     (each stage optional; pool and up exclusive)
+ * Ho = (pool ? ceil(H/2) : up ? 2H : H) + 2*pad.  NCHW-contiguous fp32, bias may be NULL.  The convolutions themselves
+ * stay on PyTorch-ROCm (MIOpen) and run bias-free.  Results are bit-identical to the PyTorch module sequence.
+ * ------------------------------------------------------------------------------------------------- */
+int optex_vgg_glue(const float* x, const float* bias, float* out, int N, int C, int H, int W, int relu, int pool, int up,
+                   int pad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement (no reference counterpart; the reference only wall-clocks forward(), optex.py:285-289).
  * When enabled, every kernel launch above is bracketed by HIP events recorded on its own stream and tallied
  * per kernel class together with its ALGORITHMIC flops / bytes.  optex_prof_collect is the only

@@ -79,7 +79,7 @@ ProfScope::~ProfScope() {
 
 static const char* kClassNames[KC_COUNT] = {"gemm_tn", "col_minmax", "col_hist", "cdf_lut", "cdf_apply", "sort_columns",
                                             "sort_match", "col_mean", "gram", "cov_finalize", "householder", "interp",
-                                            "sort_radix_sweep"};
+                                            "sort_radix_sweep", "vgg_glue"};
 
 }  // namespace optex
 

@@ -179,6 +179,21 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0):
     return x
 
 
+def vgg_glue(x, bias=None, relu=False, pool=False, up=False, pad=0):
+    """pad(up(pool(relu(x + bias)))) in one pass over an NCHW fp32 tensor (vgg.py's module glue, see include/optex.h)"""
+    x = _f32c(x).contiguous()
+    n, c, h, w = x.shape
+    hm = (h + 1) // 2 if pool else (2 * h if up else h)
+    wm = (w + 1) // 2 if pool else (2 * w if up else w)
+    out = torch.empty((n, c, hm + 2 * pad, wm + 2 * pad), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = _f32c(bias).contiguous()
+        assert bias.numel() == c
+    check(_lib.lib().optex_vgg_glue(ptr(x), ptr(bias), ptr(out), n, c, h, w, int(relu), int(pool), int(up), int(pad),
+                                    stream_ptr()))
+    return out
+
+
 def profile_enable(on=True):
     check(_lib.lib().optex_prof_enable(int(bool(on))))
 

@@ -53,6 +53,43 @@ def _synthetic_init(model: nn.Sequential, seed: int):
                 m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.05)
 
 
+def run_fused(model: nn.Sequential, x):
+    """Run one of the Sequentials above with every convolution on MIOpen (bias-free) and everything BETWEEN two
+    convolutions — bias, ReLU, max-pool / upsample, reflection pad — in one pass of optex_vgg_glue (csrc/glue.hip).
+    Bit-identical to model(x): only the kernel boundaries move."""
+    from . import ops
+    cur, bias = x, None
+    relu = pool = up = False
+    pad = 0
+
+    def flush():
+        nonlocal cur, bias, relu, pool, up, pad
+        if bias is not None or relu or pool or up or pad:
+            cur = ops.vgg_glue(cur, bias, relu=relu, pool=pool, up=up, pad=pad)
+        bias, relu, pool, up, pad = None, False, False, False, 0
+
+    for m in model:
+        if isinstance(m, nn.Conv2d):
+            flush()
+            cur = torch.nn.functional.conv2d(cur, m.weight, None)
+            bias = m.bias
+        elif isinstance(m, nn.ReLU):
+            assert not (pool or up or pad), "glue order is bias, relu, pool / upsample, pad"
+            relu = True
+        elif isinstance(m, nn.MaxPool2d):
+            assert not (up or pad)
+            pool = True
+        elif isinstance(m, nn.UpsamplingNearest2d):
+            assert not (pool or pad)
+            up = True
+        elif isinstance(m, nn.ReflectionPad2d):
+            pad = 1
+        else:
+            raise TypeError(f"unexpected module {type(m).__name__} in the VGG codec")
+    flush()
+    return cur
+
+
 class _Codec(nn.Module):
     FILE = ""
 
@@ -78,6 +115,8 @@ class Encoder(_Codec):
 
     def features(self, x):
         """NCHW image -> NCHW feature (channel-major per image: the layout every OT kernel wants)"""
+        if x.is_cuda and not torch.is_grad_enabled():
+            return run_fused(self.model, x)
         return self.model(x)
 
     def forward(self, x):
@@ -91,6 +130,8 @@ class Decoder(_Codec):
         super().__init__(depth, decoder_layers(depth), models_dir, seed=200)
 
     def decode(self, feat_nchw):
+        if feat_nchw.is_cuda and not torch.is_grad_enabled():
+            return run_fused(self.model, feat_nchw)
         return self.model(feat_nchw)
 
     def forward(self, x):

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--ns", type=int, default=12288)
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--only", type=str, default="gemm,cdf,sort,linear,loop")
+    ap.add_argument("--only", type=str, default="gemm,cdf,sort,linear,glue,loop")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     S, C, n, ns = args.S, args.C, args.n, args.ns
@@ -86,6 +86,13 @@ def main():
         report(tag + "_sort_kv_ties", timed(lambda: ops.sort_columns(x), reps=5))
     if "linear" in only:
         report(tag + "_linear", timed(lambda: ops.linear_stats(Seg.of(y), pool=False), reps=5))
+    if "glue" in only:
+        img = torch.randn((S, 64, 512, 512), device=dev, generator=g)
+        bias = torch.randn(64, device=dev, generator=g)
+        report("S%d_64x512x512_glue_relu_pad" % S, timed(lambda: ops.vgg_glue(img, bias, relu=True, pad=1), reps=10))
+        report("S%d_64x512x512_glue_relu_pool_pad" % S, timed(lambda: ops.vgg_glue(img, bias, relu=True, pool=True, pad=1), reps=10))
+        half = img[:, :, :256, :256].contiguous()
+        report("S%d_64x256x256_glue_relu_up_pad" % S, timed(lambda: ops.vgg_glue(half, bias, relu=True, up=True, pad=1), reps=10))
     if "loop" in only:
         xx = x.clone()
         report(tag + "_loop_cdf", timed(lambda: ops.ot_loop("cdf", xx, style, R32, Rt32), reps=3, warm=1))

@@ -539,3 +539,95 @@ def test_determinism_same_input_same_bits(dev):
     m1 = ops.linear_stats(Seg.of(x), pool=False)
     m2 = ops.linear_stats(Seg.of(x), pool=False)
     assert torch.equal(m1[0], m2[0]) and torch.equal(m1[1], m2[1])
+
+
+# ================================================================================================ N3 VGG glue
+@pytest.mark.parametrize("N,C,H,W", [(1, 3, 8, 8), (2, 5, 17, 9), (1, 64, 64, 48), (2, 8, 33, 31)])
+@pytest.mark.parametrize("relu,pool,up,pad", [(False, False, False, 1), (True, False, False, 1), (True, True, False, 1),
+                                               (True, False, True, 1), (True, False, False, 0), (True, True, False, 0),
+                                               (False, False, True, 0)])
+def test_vgg_glue_matches_torch_modules_bit_exact(dev, N, C, H, W, relu, pool, up, pad):
+    """csrc/glue.hip against the nn module sequence it replaces (vgg.py:14-135), odd sizes included (ceil_mode pool)"""
+    from optimaltextures_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + C * 100 + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    b = torch.randn(C, generator=g)
+    want = x + b.view(1, -1, 1, 1)
+    if relu:
+        want = torch.relu(want)
+    if pool:
+        want = torch.nn.functional.max_pool2d(want, 2, 2, 0, ceil_mode=True)
+    if up:
+        want = torch.nn.functional.interpolate(want, scale_factor=2, mode="nearest")
+    if pad:
+        want = torch.nn.functional.pad(want, (1, 1, 1, 1), mode="reflect")
+    got = ops.vgg_glue(x.to(dev), b.to(dev), relu=relu, pool=pool, up=up, pad=pad).cpu()
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+    if not (relu or pool or up):  # bias-free pad-only form (decoder input)
+        assert torch.equal(ops.vgg_glue(x.to(dev), None, pad=pad).cpu(),
+                           torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect") if pad else x)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
+def test_vgg_codec_fused_path_equals_module_path(dev, depth):
+    """Encoder.features / Decoder.decode through the fused glue == the plain nn.Sequential on the same device"""
+    from optimaltextures_amd.vgg import Decoder, Encoder
+    enc, dec = Encoder(depth).to(dev).eval(), Decoder(depth).to(dev).eval()
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(depth)).to(dev)
+    with torch.inference_mode():
+        f_fused, f_plain = enc.features(x), enc.model(x)
+        # the conv runs bias-free + our add vs MIOpen's own bias handling: same fp32 add, allow 1 ulp-level noise only
+        assert torch.allclose(f_fused, f_plain, rtol=0, atol=1e-5 * float(f_plain.abs().max()))
+        d_fused, d_plain = dec.decode(f_plain), dec.model(f_plain)
+        assert d_fused.shape == d_plain.shape == x.shape
+        assert torch.allclose(d_fused, d_plain, rtol=0, atol=1e-5 * float(d_plain.abs().max()))
+
+
+# ================================================================================================ N1 / N2 "next" rows
+def test_fit_pca_golden(dev, golden):
+    """optex.py:180-190 (quirks: scalar-mean centring, uncentred projection, off-by-one k): same k, same subspace"""
+    from optimaltextures_amd.driver import fit_pca
+    g = golden("next_rows.npz")
+    feats, eig = fit_pca(cu(g["pca_in"], dev))
+    assert eig.shape[1] == int(g["pca_k"])
+    e, want_e = eig.cpu().numpy().astype(np.float64), g["pca_eigvecs"].astype(np.float64)
+    # singular vectors are defined up to sign: compare the projectors onto the kept subspace, and |cos| per component
+    assert np.abs(e @ e.T - want_e @ want_e.T).max() < 2e-4
+    assert np.all(np.abs(np.sum(e * want_e, axis=0)) > 1 - 1e-4)
+    signs = np.sign(np.sum(e * want_e, axis=0)).astype(np.float32)
+    assert maxrel(feats.cpu().numpy() * signs, g["pca_features"]) < 1e-4
+
+
+@pytest.mark.parametrize("mode,tol", [("chol", LIN_TOL), ("cdf", 0.0)])
+def test_mix_style_features_golden(dev, golden, mode, tol):
+    """optex.py:193-206 through the boundary (two hist_match calls, un-rotated features with ReLU ties)"""
+    from optimaltextures_amd.driver import mix_style_features
+    g = golden("next_rows.npz")
+    out = mix_style_features([cu(g["mix_style"], dev)], cu(g["mix_mask"], dev), 0.5, mode)[0].cpu().numpy()
+    want = g[f"mix_out_{mode}"]
+    if mode == "cdf":   # identical un-rotated inputs: the cdf pipeline is bit-exact, the blend arithmetic is plain fp32
+        assert np.abs(out - want).max() <= 1e-6 * np.abs(want).max()
+    else:
+        assert maxrel(out, want) < tol
+
+
+def test_driver_loop_equals_oracle_chain(dev):
+    """driver.ot_iterations (independent segments, shared rotation stream, content blend) == the same chain of oracle
+    calls, bit for bit in cdf mode"""
+    from optimaltextures_amd.driver import ot_iterations
+    rng = np.random.default_rng(3)
+    S, C, n, ns, iters = 3, 32, 1024, 640, 4
+    x = relu_feat(rng, S, C, n, scale=2.0)
+    sty = relu_feat(rng, 1, C, ns, scale=1.5, shift=0.3)
+    content = relu_feat(rng, S, C, n, scale=2.0)
+    got = ot_iterations(cu(x, dev), cu(sty, dev), "cdf", iters, content=cu(content, dev), strength=0.025,
+                        rng=np.random.RandomState(11)).cpu().numpy()
+    lr = orc.LegacyRNG(11)
+    Rs = [orc.random_rotation(C, lr).astype(np.float32) for _ in range(iters)]
+    for s in range(S):
+        w = x[s]
+        for R in Rs:
+            w = orc.content_blend(orc.unrotate_cm(orc.cdf_match(orc.rotate_cm(w, R), orc.rotate_cm(sty[0], R)), R),
+                                  content[s], 0.025)
+        assert biteq(got[s], w), f"segment {s}"
