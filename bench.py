@@ -49,14 +49,28 @@ def make_texturizer(hist_mode, device):
                           independent=True).to(device).eval()
 
 
-def roofline_of(name, rec):
+def pmc_traffic():
+    """HBM-side bytes per launch per kernel class from the committed rocprofv3 PMC passes of this same command
+    (profiles/pmc_traffic.json, produced by scripts/gpu_pmc_traffic.sh + scripts/summarize_pmc.py).  The counters cannot
+    be read from inside the process, so the numbers are those of the profiled run of the same workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    try:
+        return {k: v.get("hbm_bytes") for k, v in json.load(open(path))["kernels"].items()}
+    except Exception:
+        return {}
+
+
+def roofline_of(name, rec, traffic=None):
     ms, launches = rec["ms"], max(rec["launches"], 1)
     if name in MFMA_CLASSES:
         achieved, peak, unit, bound = rec["flops"] / (ms * 1e9), PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"
     else:
         achieved, peak, unit, bound = rec["bytes"] / (ms * 1e6), PEAK_HBM_GBS, "GB/s", "hbm"
     return {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": None, "launches": rec["launches"],
+            "frac": round(achieved / peak, 4), "traffic": (round(traffic[name]) if traffic and traffic.get(name) else None),
+            "algorithmic_bytes": round(rec["bytes"] / launches), "launches": rec["launches"],
             "avg_us": round(1e3 * ms / launches, 3)}
 
 
@@ -176,8 +190,10 @@ def main():
                    "textures_per_gpu_per_step": B, "hist_mode": args.hist_mode, "parallelism": f"textures x{world}",
                    "rotation_sharing": "one sequence per rank and step"},
     }
+    traffic = pmc_traffic()
     if prof:
-        kernels = sorted((roofline_of(k, v) for k, v in prof.items() if v["ms"] > 0), key=lambda r: -r["avg_us"] * r["launches"])
+        kernels = sorted((roofline_of(k, v, traffic) for k, v in prof.items() if v["ms"] > 0),
+                         key=lambda r: -r["avg_us"] * r["launches"])
         result["roofline"] = {k: v for k, v in kernels[0].items()}
         result["kernels"] = kernels
         hot_ms = sum(v["ms"] for v in prof.values()) / args.steps
@@ -194,10 +210,19 @@ def main():
                 m.rng = np.random.RandomState(1000)
                 step(m)  # warm-up (MIOpen/rocSOLVER handles)
                 torch.cuda.synchronize()
+                if mode == "sort" and not args.no_kernel_timing:
+                    ops.profile_collect()
+                    ops.profile_enable(True)
                 t0 = time.perf_counter()
                 step(m)
                 torch.cuda.synchronize()
                 by_mode[mode] = round(B / (time.perf_counter() - t0), 3)
+                if mode == "sort" and not args.no_kernel_timing:
+                    ops.profile_enable(False)
+                    sp = ops.profile_collect()
+                    # the second half of BASELINE.json's metric: "sort HBM GB/s" (12 algorithmic bytes per element)
+                    result["sort_kernels"] = [roofline_of(k, v, traffic) for k, v in sp.items()
+                                              if k.startswith("sort") and v["ms"] > 0 and v["bytes"] > 0]
         result["textures_per_s_by_hist_mode"] = by_mode
         if not args.no_cpu_baseline:
             # more threads than ~32 only add oversubscription to torch-CPU convs and the OpenMP oracle (measured on the

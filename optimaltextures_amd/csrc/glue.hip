@@ -21,7 +21,7 @@ struct GlueArgs {
     int C, H, W;          // input plane
     int Hm, Wm;           // after pool / upsample
     int Ho, Wo;           // after padding
-    int relu, pool, up, pad;
+    int relu, pool, up, pad, vec2;
 };
 
 __device__ __forceinline__ int reflect_index(int i, int n) {  // reflection without repeating the border, |i| < n
@@ -48,28 +48,26 @@ __global__ __launch_bounds__(256) void glue_kernel(GlueArgs a) {
         int my = reflect_index(oy - a.pad, a.Hm);
         if (a.up) my >>= 1;
         float* __restrict__ orow = o + (size_t)oy * a.Wo;
-        if (POOL) {
-            const int y0 = 2 * my;
-            const bool y1 = y0 + 1 < a.H;
-            const float* __restrict__ r0 = xin + (size_t)y0 * a.W;
-            const float* __restrict__ r1 = r0 + (y1 ? a.W : 0);
-            for (int ox = lane; ox < a.Wo; ox += 64) {
+        const int sh = a.up ? 1 : 0;
+        const int y0 = POOL ? 2 * my : my;
+        const float* __restrict__ r0 = xin + (size_t)y0 * a.W;
+        const float* __restrict__ r1 = r0 + ((POOL && y0 + 1 < a.H) ? a.W : 0);   // ceil_mode: partial windows at odd edges
+        auto value = [&](int ox) {
+            float v;
+            if (POOL) {
                 const int x0 = 2 * reflect_index(ox - a.pad, a.Wm);
-                const int x1 = (x0 + 1 < a.W) ? x0 + 1 : x0;   // ceil_mode: partial windows at odd edges
-                float v = fmaxf(fmaxf(r0[x0], r0[x1]), fmaxf(r1[x0], r1[x1]));
-                v = v + b;                    // max(x_i) + b == max(x_i + b): the add is monotone
-                if (a.relu) v = fmaxf(v, 0.f);
-                orow[ox] = v;
+                const int x1 = (x0 + 1 < a.W) ? x0 + 1 : x0;
+                v = fmaxf(fmaxf(r0[x0], r0[x1]), fmaxf(r1[x0], r1[x1])) + b;  // max(x_i) + b == max(x_i + b)
+            } else {
+                v = r0[reflect_index(ox - a.pad, a.Wm) >> sh] + b;
             }
+            return a.relu ? fmaxf(v, 0.f) : v;
+        };
+        if (a.vec2) {  // even row length and 8-byte aligned planes: 8-byte stores (the glue is store-bound)
+            for (int ox = 2 * lane; ox < a.Wo; ox += 128)
+                *reinterpret_cast<float2*>(orow + ox) = make_float2(value(ox), value(ox + 1));
         } else {
-            const float* __restrict__ r0 = xin + (size_t)my * a.W;
-            const int sh = a.up ? 1 : 0;
-            for (int ox = lane; ox < a.Wo; ox += 64) {
-                const int mx = reflect_index(ox - a.pad, a.Wm) >> sh;
-                float v = r0[mx] + b;
-                if (a.relu) v = fmaxf(v, 0.f);
-                orow[ox] = v;
-            }
+            for (int ox = lane; ox < a.Wo; ox += 64) orow[ox] = value(ox);
         }
     }
 }
@@ -92,6 +90,7 @@ extern "C" int optex_vgg_glue(const float* x, const float* bias, float* out, int
     a.Ho = a.Hm + 2 * pad;
     a.Wo = a.Wm + 2 * pad;
     a.relu = relu; a.pool = pool; a.up = up; a.pad = pad;
+    a.vec2 = (a.Wo % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);
     if (pad && (a.Hm < 2 || a.Wm < 2)) {
         set_error("optex_vgg_glue: reflection padding needs at least 2 pixels per side (got %d x %d)", a.Hm, a.Wm);
         return OPTEX_E_ARG;

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes over bench.py (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; separate runs as
+the MI355X guide prescribes) into profiles/<name>.json: average HBM-side bytes per launch for every optex kernel class
+in the TIMED steps.
+
+    python scripts/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> --out profiles/x.json
+
+Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB... the counters report kilobytes
+(x 1024 here); on gfx950 FETCH_SIZE counts 128-byte requests at 64 bytes for wide coalesced streaming reads, so it is
+DOUBLED; WRITE_SIZE matched known byte counts in our own access patterns (checked on the rotation GEMM, the LUT apply
+and the sort: written bytes == output size) and is used as is.  Infinity-cache hits are included in both.
+"""
+import argparse
+import collections
+import csv
+import json
+import re
+
+CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"), ("col_hist_kernel", "col_hist"),
+            ("col_minmax_kernel", "col_minmax"), ("cdf_lut_kernel", "cdf_lut"), ("glue_kernel", "vgg_glue"),
+            ("rank_columns_kernel", "sort_rank"), ("sort_columns_kernel", "sort_radix"), ("gram_kernel", "gram"),
+            ("col_mean_kernel", "col_mean"), ("householder_apply", "householder")]
+
+
+def classify(name):
+    for key, cls in CLASS_OF:
+        if key in name:
+            if cls == "sort_rank":
+                m = re.search(r"rank_columns_kernel<\d+, (\d)>", name)
+                return "sort_match" if m and m.group(1) == "1" else "sort_columns"
+            return cls
+    return None
+
+
+def timed_rows(path, warmup):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "distribution_elementwise_grid_stride_kernel" in r["Kernel_Name"]]
+    starts.append(len(rows))
+    steps = [(a, b) for a, b in zip(starts[:-1], starts[1:])
+             if sum("householder_prep" in r["Kernel_Name"] for r in rows[a:b]) >= 5]
+    steps = steps[warmup:]
+    return [r for a, b in steps for r in rows[a:b]], len(steps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_csv")
+    ap.add_argument("write_csv")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--command", default="")
+    args = ap.parse_args()
+    out = {"command": args.command, "units": "bytes per launch, averaged over the launches of the timed steps",
+           "corrections": {"FETCH_SIZE": "x1024 x2 (gfx950 counts 128-B requests as 64 B on wide streaming reads)",
+                           "WRITE_SIZE": "x1024"}, "kernels": {}}
+    for path, counter, scale in ((args.fetch_csv, "FETCH_SIZE", 2048.0), (args.write_csv, "WRITE_SIZE", 1024.0)):
+        rows, nsteps = timed_rows(path, args.warmup)
+        agg = collections.defaultdict(list)
+        for r in rows:
+            if r["Counter_Name"] != counter:
+                continue
+            cls = classify(r["Kernel_Name"])
+            if cls:
+                agg[cls].append(float(r["Counter_Value"]) * scale)
+        for cls, vals in agg.items():
+            e = out["kernels"].setdefault(cls, {})
+            e[counter.lower() + "_bytes"] = sum(vals) / len(vals)
+            e["launches_" + counter.lower()] = len(vals)
+        out["timed_steps"] = nsteps
+    for cls, e in out["kernels"].items():
+        e["hbm_bytes"] = e.get("fetch_size_bytes", 0.0) + e.get("write_size_bytes", 0.0)
+    json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
