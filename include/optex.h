@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 1
+#define OPTEX_ABI_VERSION 2
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -132,11 +132,16 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
  * x is [n_seg, C, n] channel-major segments, updated in place; style is [src_n_seg, C, ns].
  * R32 / Rt32 are [iters, C, C] as produced by optex_rotations_from_normals.
  * mode: 0 = cdf, 1 = sort.
+ * fuse_rotations = 0: the literal sequence above (three feature-map GEMMs per iteration, like the reference).
+ * fuse_rotations = 1 (content must be NULL): `(m @ R_i^T) @ R_{i+1}` is evaluated as `m @ (R_i^T R_{i+1})` — the same
+ *   product re-associated, one feature-map GEMM per iteration instead of two; agrees with the literal loop to fp32
+ *   round-off per step.  An optional fast path, never the default.
  * ------------------------------------------------------------------------------------------------- */
-size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg);
+size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters,
+                              int fuse_rotations);
 int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
                   const float* R32, const float* Rt32, int iters, const float* content, float strength,
-                  void* ws, void* stream);
+                  int fuse_rotations, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * N3  element-wise glue between the VGG convolutions, vgg.py:14-135: conv bias add, nn.ReLU,

@@ -34,73 +34,9 @@
 //    specification-conformant fallback for every input.
 #include <cstdlib>
 
-#include "optex_common.h"
+#include "sort_common.h"
 
 namespace optex {
-
-constexpr int SORT_NT = 1024;            // 16 wavefronts
-constexpr int SORT_NW = SORT_NT / 64;
-constexpr int SORT_RADIX = 256;
-constexpr int SORT_MAX_N = 16384;
-constexpr int SORT_CSTR = SORT_RADIX + 1;
-
-constexpr int RK_COARSE = 256;           // equalisation bins
-constexpr int RK_BIG = 48;               // buckets above this size take the all-equal path or the radix fallback
-constexpr int RK_MAXBIG = 8;
-constexpr int RK_MIN_N = 512;            // shorter columns go straight to the radix kernel
-
-enum SortMode { SORT_EMIT = 0, SORT_MATCH = 1 };
-
-struct SortArgs {
-    const float* keys; long ld, ss; long n; int C; int x_n_seg;
-    float* out_keys; uint32_t* out_idx;                       // SORT_EMIT, contiguous [n_seg, C, n]
-    const float* src_sorted; long ns; int src_n_seg;          // SORT_MATCH: sorted source keys [src_n_seg, C, ns]
-    float* out; long ldo, oss;                                // SORT_MATCH
-    int* flags;                                               // per column: 1 = needs the radix kernel
-    int only_flagged;                                         // radix kernel: skip columns whose flag is 0
-    double inv_2nt;                                           // 1 / (2 * n) for the quantile index
-    int ncols;                                                // C * n_seg
-#ifdef OPTEX_SORT_PROBE
-    long long* probe;                                         // [ncols, 16] phase timestamps (scripts/sort_phase_probe.hip)
-#endif
-};
-
-#ifdef OPTEX_SORT_PROBE
-#define SORT_PROBE(i) do { if (threadIdx.x == 0) a.probe[(size_t)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
-#else
-#define SORT_PROBE(i) do { } while (0)
-#endif
-
-// floor((2 * rank + 1) * ns / (2 * nt)), exact: the quotient is < 2^24, a non-integer quotient is at least 2^-15 away
-// from an integer, the double product carries < 2^-28 of error and the 2^-27 bias lifts exact integers over the edge.
-__device__ __forceinline__ unsigned quantile_index(unsigned rank, unsigned ns, unsigned nt, double inv_2nt) {
-    if (ns == nt) return rank;
-    const double a = (double)(2u * rank + 1u) * (double)ns;
-    return (unsigned)__builtin_fma(a, inv_2nt, 7.450580596923828e-09);
-}
-
-// block-wide exclusive scan of one value per thread (all SORT_NT threads must call); red: >= 17 words of LDS scratch
-__device__ __forceinline__ unsigned block_excl_scan(unsigned v, uint32_t* red, unsigned* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) red[w] = incl;
-    __syncthreads();
-    unsigned base = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < SORT_NW; k++) {
-        const unsigned x = red[k];
-        if (k < w) base += x;
-        tot += x;
-    }
-    __syncthreads();
-    if (total) *total = tot;
-    return base + incl - v;
-}
 
 // ================================================================================================ rank kernel
 // LDS map (ITEMS = 16: ~150 KiB): grouped keys gk [CAP] u32, their pixel indices gi [CAP] u16, rank by pixel rk [CAP] u16
@@ -439,18 +375,6 @@ static constexpr size_t rank_lds_bytes(bool match) {
 }
 
 // ================================================================================================ radix kernel
-// lanes holding the same 8-bit digit: 8 ballots
-__device__ __forceinline__ unsigned long long match_digit(unsigned d) {
-    unsigned long long m = ~0ull;
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
-    }
-    return m;
-}
-
 template <int ITEMS, int MODE>
 __global__ __launch_bounds__(SORT_NT) void sort_columns_kernel(SortArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -642,35 +566,36 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
     return check_launch("sort_columns_kernel");
 }
 
+static size_t flags_bytes(int ncols) { return align_up(sizeof(int) * (size_t)ncols, 256); }
+
 template <int MODE>
-static int launch_sort(const SortArgs& a, int ncols, int* flags, hipStream_t st) {
+static int launch_sort(const SortArgs& a, int ncols, int* flags, void* large_ws, hipStream_t st) {
     if (a.n <= 2 * SORT_NT) return launch_sort_items<2, MODE>(a, ncols, flags, st);
     if (a.n <= 4 * SORT_NT) return launch_sort_items<4, MODE>(a, ncols, flags, st);
     if (a.n <= 8 * SORT_NT) return launch_sort_items<8, MODE>(a, ncols, flags, st);
     if (a.n <= 16 * SORT_NT) return launch_sort_items<16, MODE>(a, ncols, flags, st);
-    set_error("sort: columns longer than %d keys are not supported yet (n = %ld)", SORT_MAX_N, a.n);
-    return OPTEX_E_UNSUPPORTED;
+    // longer than one LDS: global multi-pass radix (sort_large.hip)
+    return sort_large(MODE, a, ncols, large_ws, st);
 }
-
-static size_t flags_bytes(int ncols) { return align_up(sizeof(int) * (size_t)ncols, 256); }
 
 int sort_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                     int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, hipStream_t st) {
-    // ws: [flags for the larger launch][sorted source keys [src_n_seg, C, ns]]
+    // ws: [flags for the larger launch][sorted source keys [src_n_seg, C, ns]][scratch of the large-column path]
     int* flags = static_cast<int*>(ws);
     float* ssorted = reinterpret_cast<float*>(static_cast<char*>(ws) + flags_bytes(C * n_seg));
+    void* large_ws = reinterpret_cast<char*>(ssorted) + align_up((size_t)src_n_seg * C * ns * sizeof(float), 256);
     // 1. sort the source columns (keys only)
     SortArgs s{};
     s.keys = source; s.ld = lds; s.ss = sss; s.n = ns; s.C = C; s.x_n_seg = src_n_seg;
     s.out_keys = ssorted; s.out_idx = nullptr;
-    int rc = launch_sort<SORT_EMIT>(s, C * src_n_seg, flags, st);
+    int rc = launch_sort<SORT_EMIT>(s, C * src_n_seg, flags, large_ws, st);
     if (rc) return rc;
     // 2. rank each target column and fetch the source quantiles
     SortArgs t{};
     t.keys = target; t.ld = ldt; t.ss = tss; t.n = nt; t.C = C; t.x_n_seg = n_seg;
     t.src_sorted = ssorted; t.ns = ns; t.src_n_seg = src_n_seg;
     t.out = out; t.ldo = ldo; t.oss = oss;
-    return launch_sort<SORT_MATCH>(t, C * n_seg, flags, st);
+    return launch_sort<SORT_MATCH>(t, C * n_seg, flags, large_ws, st);
 }
 
 }  // namespace optex
@@ -678,8 +603,7 @@ int sort_match_impl(const float* target, long ldt, long tss, long nt, const floa
 using namespace optex;
 
 extern "C" size_t optex_sort_ws_bytes(long n, int C, int n_seg) {
-    (void)n;
-    return flags_bytes(C * n_seg);
+    return flags_bytes(C * n_seg) + (n > SORT_MAX_N ? sort_large_ws_bytes(n, C * n_seg) : 0);
 }
 
 extern "C" int optex_sort_columns(const float* keys, long ld, long seg_stride, long n, int C, int n_seg,
@@ -691,12 +615,17 @@ extern "C" int optex_sort_columns(const float* keys, long ld, long seg_stride, l
     SortArgs a{};
     a.keys = keys; a.ld = ld; a.ss = seg_stride; a.n = n; a.C = C; a.x_n_seg = n_seg;
     a.out_keys = out_keys; a.out_idx = out_idx;
-    return launch_sort<SORT_EMIT>(a, C * n_seg, static_cast<int*>(ws), as_stream(stream));
+    void* large_ws = ws ? static_cast<char*>(ws) + flags_bytes(C * n_seg) : nullptr;
+    return launch_sort<SORT_EMIT>(a, C * n_seg, static_cast<int*>(ws), large_ws, as_stream(stream));
 }
 
 extern "C" size_t optex_sort_match_ws_bytes(long nt, long ns, int C, int n_seg, int src_n_seg) {
-    (void)nt;
-    return flags_bytes(C * (n_seg > src_n_seg ? n_seg : src_n_seg)) + align_up((size_t)src_n_seg * C * ns * sizeof(float), 256);
+    // [flags][sorted source keys][scratch of the large-column path, shared by the source and the target sort]
+    size_t large = 0;
+    if (nt > SORT_MAX_N) large = sort_large_ws_bytes(nt, C * n_seg);
+    if (ns > SORT_MAX_N && sort_large_ws_bytes(ns, C * src_n_seg) > large) large = sort_large_ws_bytes(ns, C * src_n_seg);
+    return flags_bytes(C * (n_seg > src_n_seg ? n_seg : src_n_seg)) + align_up((size_t)src_n_seg * C * ns * sizeof(float), 256) +
+           large;
 }
 
 extern "C" int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt, const float* source,

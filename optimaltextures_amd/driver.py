@@ -104,7 +104,7 @@ def hls_to_rgb(img: Tensor) -> Tensor:
 
 # ------------------------------------------------------------------------------------------------ the hot loop
 def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content: Optional[Tensor] = None,
-                  strength: float = 0.0, pooled: bool = False, rng=None) -> Tensor:
+                  strength: float = 0.0, pooled: bool = False, rng=None, fuse_rotations: bool = False) -> Tensor:
     """`iters` sliced-OT steps (optex.py:112-117) on channel-major segments.  x [S, C, n] is updated in place and
     returned; style [1 or S, C, ns]; content None or [S, C, n].  pooled=True reproduces the reference's batch
     semantics (all S images form ONE distribution per channel); otherwise segments are independent textures."""
@@ -117,7 +117,8 @@ def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content:
     if pooled and s > 1:
         return _pooled_iterations(x, style, hist_mode, R32, Rt32, content, strength)
     if hist_mode in LOOP_MODES:
-        return ops.ot_loop(hist_mode, x, style, R32, Rt32, content=content, strength=strength)
+        return ops.ot_loop(hist_mode, x, style, R32, Rt32, content=content, strength=strength,
+                           fuse_rotations=fuse_rotations)
     if hist_mode not in LINEAR_MODES:
         raise ValueError(f"hist_mode must be one of chol|pca|sym|cdf|sort, got {hist_mode!r}")
     ss = style.shape[0]
@@ -164,7 +165,8 @@ class OptimalTexture(torch.nn.Module):
     def __init__(self, size: int = 512, iters: int = 500, passes: int = 5, hist_mode: str = "chol",
                  color_transfer: Optional[str] = None, content_strength: float = 0.1, style_scale: float = 1,
                  mixing_alpha: float = 0.5, no_pca: bool = False, no_multires: bool = False,
-                 layers=(5, 4, 3, 2, 1), models_dir: Optional[str] = None, independent: bool = False):
+                 layers=(5, 4, 3, 2, 1), models_dir: Optional[str] = None, independent: bool = False,
+                 fuse_rotations: bool = False):
         super().__init__()
         self.hist_mode = hist_mode
         self.color_transfer = color_transfer
@@ -173,6 +175,7 @@ class OptimalTexture(torch.nn.Module):
         self.mixing_alpha = mixing_alpha
         self.use_pca = not no_pca
         self.independent = independent
+        self.fuse_rotations = fuse_rotations  # optional re-association (m @ R^T) @ R' -> m @ (R^T R'), cdf / sort only
         self.passes = passes
         self.iters_per_pass_and_layer, self.sizes = get_iters_and_sizes(size, iters, passes, not no_multires)
         self.layers = tuple(sorted({int(l) for l in layers}, reverse=True))
@@ -252,7 +255,7 @@ class OptimalTexture(torch.nn.Module):
                 x = ot_iterations(x, style_features[li], self.hist_mode,
                                   layer_iters(self.iters_per_pass_and_layer, p, enc_index),
                                   content=content_features[li] if blend else None, strength=strength,
-                                  pooled=not self.independent, rng=self.rng)
+                                  pooled=not self.independent, rng=self.rng, fuse_rotations=self.fuse_rotations)
                 if self.use_pca:
                     x = unproject_cm(x, style_eigvs[li].t().contiguous())
                 pastiche = decoder.decode(x.view(b, -1, h, w))

@@ -162,8 +162,10 @@ def rotations_from_normals(normals, N, count, device, want64=False):
     return (R32, Rt32, R64) if want64 else (R32, Rt32)
 
 
-def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0):
-    """optex.py:112-117 fused on device for mode in {"cdf", "sort"}; x [S, C, n] is updated IN PLACE."""
+def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False):
+    """optex.py:112-117 fused on device for mode in {"cdf", "sort"}; x [S, C, n] is updated IN PLACE.
+    fuse_rotations: evaluate (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (one GEMM per iteration instead of two; fp32
+    round-off differences only; needs content=None)."""
     lib = _lib.lib()
     S, C, n = x.shape
     Ss, Cs, ns = style.shape
@@ -173,9 +175,10 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0):
     if content is not None:
         assert content.shape == x.shape and content.is_contiguous()
     m = LOOP_MODES[mode]
-    ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss), x.device)
+    fuse = int(bool(fuse_rotations) and content is None)
+    ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse), x.device)
     check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), iters,
-                            ptr(content), ctypes.c_float(strength), ptr(ws), stream_ptr()))
+                            ptr(content), ctypes.c_float(strength), fuse, ptr(ws), stream_ptr()))
     return x
 
 

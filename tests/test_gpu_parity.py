@@ -285,10 +285,33 @@ def test_sort_full_size_properties(dev):
     assert biteq(idx[3, 5:9].cpu().numpy().astype(np.uint32), oi)
 
 
-def test_sort_too_long_column_is_a_clean_error(dev):
+@pytest.mark.parametrize("S,C,n", [(1, 3, 16385), (2, 2, 40000), (1, 2, 262144)])
+def test_sort_long_columns_global_radix_bit_exact(dev, S, C, n):
+    """columns longer than one LDS (1024^2 / 2048^2 feature maps): csrc/sort_large.hip, same specification"""
     from optimaltextures_amd import ops
-    with pytest.raises(RuntimeError, match="not supported"):
-        ops.sort_columns(torch.zeros((1, 1, 16385), device=dev))
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((S, C, n)).astype(np.float32)
+    x[0, 0] = np.maximum(x[0, 0], 0)                       # ~50 % ties
+    x[0, 1, :6] = [-0.0, 0.0, np.inf, -np.inf, 1e-42, np.nan]
+    keys, idx = ops.sort_columns(cu(x, dev))
+    keys, idx = keys.cpu().numpy(), idx.cpu().numpy().view(np.uint32)
+    for s in range(S):
+        ok, oi = orc.sort_columns(x[s])
+        assert biteq(idx[s], oi), "sort indices must be bit-exact (stable)"
+        assert biteq(keys[s].view(np.uint32), ok.view(np.uint32))
+
+
+@pytest.mark.parametrize("nt,ns", [(20000, 16384), (16384, 30000), (65536, 49152)])
+def test_sort_match_long_columns_bit_exact(dev, nt, ns):
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    rng = np.random.default_rng(nt + ns)
+    t = rng.standard_normal((2, 3, nt)).astype(np.float32)
+    s = (rng.standard_normal((1, 3, ns)) * 2 + 1).astype(np.float32)
+    t[0, 0] = np.maximum(t[0, 0], 0)
+    out = ops.sort_match_seg(Seg.of(cu(t, dev)), Seg.of(cu(s, dev))).cpu().numpy()
+    for k in range(2):
+        assert biteq(out[k], orc.sort_match(t[k], s[0]))
 
 
 # ================================================================================================ K4 linear stats
@@ -631,3 +654,37 @@ def test_driver_loop_equals_oracle_chain(dev):
             w = orc.content_blend(orc.unrotate_cm(orc.cdf_match(orc.rotate_cm(w, R), orc.rotate_cm(sty[0], R)), R),
                                   content[s], 0.025)
         assert biteq(got[s], w), f"segment {s}"
+
+
+# ================================================================================================ optional fused rotations
+@pytest.mark.parametrize("mode", ["cdf", "sort"])
+def test_ot_loop_fused_rotations(dev, mode):
+    """fuse_rotations re-associates (m @ R_i^T) @ R_{i+1} = m @ (R_i^T R_{i+1}).  (1) the HIP loop equals the oracle's
+    restatement of exactly that algorithm bit for bit; (2) the re-associated product itself differs from the literal
+    two-GEMM product only by fp32 round-off (<= 2e-6 * max), which is the whole numerical content of the option."""
+    from optimaltextures_amd import ops
+    rng = np.random.default_rng(17)
+    S, C, n, ns, iters = 2, 32, 1024, 768, 4
+    x = relu_feat(rng, S, C, n, scale=2.0)
+    sty = relu_feat(rng, 1, C, ns, scale=1.5, shift=0.2)
+    lr = orc.LegacyRNG(5)
+    R = np.stack([orc.random_rotation(C, lr) for _ in range(iters)]).astype(np.float32)
+    Rt = np.ascontiguousarray(R.transpose(0, 2, 1))
+    xd = cu(x, dev)
+    ops.ot_loop(mode, xd, cu(sty, dev), cu(R, dev), cu(Rt, dev), fuse_rotations=True)
+    got = xd.cpu().numpy()
+    match = orc.cdf_match if mode == "cdf" else orc.sort_match
+    P = [orc.gemm_tn(R[i], R[i + 1]) for i in range(iters - 1)]
+    for s in range(S):
+        y = orc.rotate_cm(x[s], R[0])
+        for i in range(iters):
+            m = match(y, orc.rotate_cm(sty[0], R[i]))
+            if i + 1 < iters:
+                y = orc.gemm_tn(P[i], m)
+            else:
+                out = orc.unrotate_cm(m, R[i])
+        assert biteq(got[s], out), f"segment {s}"
+    m = relu_feat(rng, C, 4096, scale=3.0)
+    literal = orc.rotate_cm(orc.unrotate_cm(m, R[0]), R[1])
+    fused = orc.gemm_tn(P[0], m)
+    assert np.abs(literal - fused).max() <= 2e-6 * np.abs(literal).max()
