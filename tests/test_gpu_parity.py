@@ -688,3 +688,72 @@ def test_ot_loop_fused_rotations(dev, mode):
     literal = orc.rotate_cm(orc.unrotate_cm(m, R[0]), R[1])
     fused = orc.gemm_tn(P[0], m)
     assert np.abs(literal - fused).max() <= 2e-6 * np.abs(literal).max()
+
+
+# ================================================================================================ end to end (driver)
+def _cpu_forward(tex_cpu, pastiche, styles, content, np_seed, mode):
+    """OptimalTexture.forward restated on the host: torch-CPU VGG (same weights), the ORACLE for every hot-path call,
+    the same rotation stream.  Mirrors optex.py:81-139 for the no_pca / single-style case."""
+    from optimaltextures_amd.util import get_size, layer_iters, resize
+    rng = orc.LegacyRNG(np_seed)
+    with torch.inference_mode():
+        for p in range(tex_cpu.passes):
+            size = tex_cpu.sizes[p]
+            if pastiche.shape[-2] != size and pastiche.shape[-1] != size:
+                sty = [resize(s, size=get_size(size, tex_cpu.style_scale, s.shape[2], s.shape[3])) for s in styles]
+                cont = None
+                cont_size = (size, size)
+                if content is not None:
+                    cont_size = get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True)
+                    cont = resize(content, size=cont_size)
+                pastiche = resize(pastiche, size=cont_size)
+            else:
+                sty, cont = styles, content
+            for enc, dec in zip(tex_cpu.encoders, tex_cpu.decoders):
+                enc_index = 5 - enc.depth
+                sf = enc.model(sty[0])[0]
+                sf = sf.reshape(sf.shape[0], -1).numpy()
+                cf = None
+                if cont is not None:
+                    cf = enc.model(cont)[0]
+                    cf = cf.reshape(cf.shape[0], -1)
+                    cf = (cf - cf.mean() + float(sf.mean())).numpy()
+                feat = enc.model(pastiche)
+                _, c, h, w = feat.shape
+                x = feat[0].reshape(c, h * w).numpy()
+                blend = cf is not None and enc_index <= 2
+                strength = tex_cpu.content_strength / 2 ** (4 - enc_index) if blend else 0.0
+                for _ in range(layer_iters(tex_cpu.iters_per_pass_and_layer, p, enc_index)):
+                    R = orc.random_rotation(c, rng).astype(np.float32)
+                    x = orc.unrotate_cm(orc.hist_match_cm(orc.rotate_cm(x, R), 1, orc.rotate_cm(sf, R), 1, mode), R)
+                    if blend:
+                        x = orc.content_blend(x, cf, strength)
+                pastiche = dec.model(torch.from_numpy(x).view(1, c, h, w))
+    return pastiche
+
+
+@pytest.mark.parametrize("mode,with_content", [("chol", False), ("chol", True), ("sort", False)])
+def test_forward_end_to_end_vs_host_restatement(dev, mode, with_content):
+    """The whole driver (multi-pass schedule, [l-1] table indexing, resize rules, scalar content re-centring, blend
+    strengths /2^(4-l), glue-fused codec, hot loop) against a host restatement built from the oracle.  Smooth modes
+    agree to fp32 noise; `sort` is checked on image statistics (a rank flip moves single pixels, not the texture)."""
+    from optimaltextures_amd.driver import OptimalTexture
+    kw = dict(size=256, iters=60, passes=2, hist_mode=mode, no_pca=True, layers=(3, 2), content_strength=0.2)
+    tex_cpu = OptimalTexture(**kw).eval()
+    tex_gpu = OptimalTexture(**kw).to(dev).eval()   # same seeded synthetic weights
+    g = torch.Generator().manual_seed(11)
+    low = torch.rand(1, 3, 12, 16, generator=g)
+    style = torch.nn.functional.interpolate(low, size=(160, 224), mode="bicubic", align_corners=False).clamp(0, 1)
+    content = torch.rand(1, 3, 256, 256, generator=g) if with_content else None
+    pastiche = torch.rand(1, 3, 256, 256, generator=g)
+    want = _cpu_forward(tex_cpu, pastiche.clone(), [style], content, 77, mode).numpy()
+    tex_gpu.rng = np.random.RandomState(77)
+    with torch.inference_mode():
+        got = tex_gpu.forward(pastiche.to(dev), [style.to(dev)], None if content is None else content.to(dev)).cpu().numpy()
+    assert got.shape == want.shape and np.isfinite(got).all()
+    if mode == "sort":
+        assert abs(got.mean() - want.mean()) < 2e-3 * np.abs(want).max()
+        assert abs(got.std() - want.std()) < 5e-3 * want.std()
+        assert np.mean(np.abs(got - want) < 1e-2 * np.abs(want).max()) > 0.98
+    else:
+        assert np.abs(got - want).max() < 2e-3 * np.abs(want).max()

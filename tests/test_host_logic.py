@@ -56,3 +56,26 @@ def test_cli_keeps_every_reference_flag():
         cli.build_parser().parse_args(["--hist_mode", "nope"])
     b = cli.build_parser().parse_args(["-s", "a.jpg", "b.jpg", "-c", "c.jpg", "--hist_mode", "cdf", "--no_pca"])
     assert b.style == ["a.jpg", "b.jpg"] and b.content == "c.jpg" and b.hist_mode == "cdf" and b.no_pca
+
+
+def test_hls_conversion_matches_colorsys_and_round_trips():
+    """driver.rgb_to_hls / hls_to_rgb stand in for kornia.color.hls (optex.py:126-131; kornia is not installed):
+    h in radians [0, 2pi), channel order (h, l, s) like kornia."""
+    import colorsys
+
+    import torch
+
+    from optimaltextures_amd.driver import hls_to_rgb, rgb_to_hls
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(2, 3, 8, 8, generator=g)
+    img[0, :, 0, 0] = 0.5          # grey pixel: hue / saturation 0
+    img[0, :, 0, 1] = torch.tensor([1.0, 0.0, 0.0])
+    hls = rgb_to_hls(img)
+    for b in range(2):
+        for y in range(8):
+            for x in range(8):
+                r, gg, bb = (float(v) for v in img[b, :, y, x])
+                h, l, s = colorsys.rgb_to_hls(r, gg, bb)
+                got = [float(v) for v in hls[b, :, y, x]]
+                assert abs(got[0] - h * 2 * np.pi) < 1e-4 and abs(got[1] - l) < 1e-6 and abs(got[2] - s) < 1e-4
+    assert torch.allclose(hls_to_rgb(hls), img, atol=1e-5)
