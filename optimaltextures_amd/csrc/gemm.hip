@@ -13,6 +13,8 @@
 //
 // Roofline: 2*M*K*n flop against 4*(K + M)*n + 4*K*M bytes; at C = 256 the intensity is 64 flop/B, i.e.
 // MFMA-bound (157 TFLOP/s fp32 matrix peak); below C ~ 80 it turns HBM-bound.
+#include <cstdlib>
+
 #include "gemm_args.h"
 
 namespace optex {
@@ -237,6 +239,118 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     }
 }
 
+// ---- Hot-loop specialisation (channel-major in / out, no epilogue extras, full pixel tiles): the same block structure
+// on v_mfma_f32_16x16x4_f32 — 4 accumulator registers per MFMA instead of 16, i.e. half the accumulator read / write
+// traffic per flop.  Bit-identical results (both MFMA shapes are k-ordered fma chains); measured 118.6 vs 116.0 TFLOP/s
+// at M = K = 256, n = 32 x 16384 (the kernel is power-limited: less register-file traffic buys clock).
+// OPTEX_GEMM_MFMA16=0 disables it.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+    constexpr int SA = BM + 16, SB = BN + 16;  // row strides = 16 mod 32 banks: the four k-rows of a fragment read hit disjoint banks
+    constexpr int NA = BK * BM / 4 / NT, NB = BK * BN / 4 / NT;
+    static_assert(NA >= 1 && NB >= 1 && NA * NT * 4 == BK * BM && NB * NT * 4 == BK * BN, "tile / thread count mismatch");
+    __shared__ float As[2][BK * SA];
+    __shared__ float Bs[2][BK * SB];
+    const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm_idx = L % a.tiles_m;
+    const int tn_idx = (L / a.tiles_m) % a.tiles_n;
+    const int seg = L / (a.tiles_m * a.tiles_n);
+    const int m0 = tm_idx * BM;
+    const long n0 = (long)tn_idx * BN;
+    const float* __restrict__ At = a.At + (size_t)seg * a.at_ss;
+    const float* __restrict__ Bp = a.B + (size_t)seg * a.b_ss;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l15 = lane & 15, kq = lane >> 4;
+    float4 ra[NA], rb[NB];
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = tid + i * NT;
+            const int k = idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + k < a.K && m + 3 < a.M) v = *reinterpret_cast<const float4*>(At + (size_t)(k0 + k) * a.lda + m);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int idx = tid + i * NT;
+            const int k = idx / (BN / 4);
+            const long nn = n0 + (idx % (BN / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + k < a.K) v = *reinterpret_cast<const float4*>(Bp + (size_t)(k0 + k) * a.ldb + nn);
+            rb[i] = v;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = tid + i * NT;
+            *reinterpret_cast<float4*>(&As[buf][(idx / (BM / 4)) * SA + (idx % (BM / 4)) * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int idx = tid + i * NT;
+            *reinterpret_cast<float4*>(&Bs[buf][(idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4]) = rb[i];
+        }
+    };
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (a.K + BK - 1) / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; kc++) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_global((kc + 1) * BK);
+        const float* as = &As[buf][kq * SA + wm * WM + l15];
+        const float* bs = &Bs[buf][kq * SB + wn * WN + l15];
+#pragma unroll
+        for (int j = 0; j < BK / 4; j++) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int t = 0; t < TM; t++) av[t] = as[(4 * j) * SA + t * 16];
+#pragma unroll
+            for (int t = 0; t < TN; t++) bv[t] = bs[(4 * j) * SB + t * 16];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (kc + 1 < nchunks) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+    float* __restrict__ Op = a.O + (size_t)seg * a.o_ss;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) {
+            const long nn = n0 + wn * WN + tn * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + wm * WM + tm * 16 + 4 * kq + r;
+                if (m < a.M) Op[(size_t)m * a.ldo + nn] = acc[tm][tn][r];
+            }
+        }
+}
+
+static int gemm_mfma16_env() {
+    static const int v = [] {
+        const char* e = getenv("OPTEX_GEMM_MFMA16");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+
 template <int BM, int BN, int BK, int WGM, int WGN, bool BPM, bool OPM>
 static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
     constexpr int NT = 64 * WGM * WGN;
@@ -267,6 +381,16 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
+        if (!BPM && !OPM && vec && gemm_mfma16_env() && !a.bsub && !a.badd && !a.content && a.n % 128 == 0 && a.M % 4 == 0 &&
+            a.M > 128 && huge >= 2LL * n_cu) {
+            a.tiles_m = (a.M + 255) / 256;
+            a.tiles_n = (int)(a.n / 128);
+            const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
+            ProfScope prof(KC_GEMM, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
+                           4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
+            hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2>), dim3((unsigned)total), dim3(512), 0, st, a);
+            return check_launch("gemm16_cm_kernel");
+        }
         if (a.M > 128 && huge >= 2LL * n_cu) return launch_cfg<256, 128, 16, 4, 2, BPM, OPM>(a, vec, st);
         return launch_cfg<128, 128, 16, 2, 2, BPM, OPM>(a, vec, st);
     }

@@ -757,3 +757,41 @@ def test_forward_end_to_end_vs_host_restatement(dev, mode, with_content):
         assert np.mean(np.abs(got - want) < 1e-2 * np.abs(want).max()) > 0.98
     else:
         assert np.abs(got - want).max() < 2e-3 * np.abs(want).max()
+
+
+# ================================================================================================ BASELINE configs 3 / 5 (shape coverage)
+def _smooth_image(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, 3, max(h // 32, 2), max(w // 32, 2), generator=g)
+    return torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False).clamp(0, 1)
+
+
+def test_config3_style_transfer_1024_runs(dev):
+    """BASELINE config 3 in miniature iterations: 1024^2 style transfer, content blend on relu3_1 (strength/4), pooled
+    B = 1, default chol, colour transfer 'opt' (3 cdf iterations on the RGB image, optex.py:131-134)"""
+    from optimaltextures_amd.driver import OptimalTexture
+    tex = OptimalTexture(size=1024, iters=40, passes=2, hist_mode="chol", content_strength=0.2, layers=(3, 2),
+                         color_transfer="opt").to(dev).eval()
+    assert tex.sizes == [256, 1024]
+    style, content = _smooth_image(416, 416, 1).to(dev), _smooth_image(1024, 1024, 2).to(dev)
+    tex.rng = np.random.RandomState(3)
+    with torch.inference_mode():
+        out = tex.forward(torch.rand(content.shape, generator=torch.Generator().manual_seed(4)).to(dev), [style], content)
+    assert out.shape == (1, 3, 1024, 1024) and bool(torch.isfinite(out).all())
+    # the content blend keeps the large-scale structure: the result correlates with the content image
+    a, b = out.mean(1).flatten() - out.mean(), content.mean(1).flatten() - content.mean()
+    assert float((a * b).sum() / (a.norm() * b.norm())) > 0.2
+
+
+def test_config5_two_style_mixing_runs(dev):
+    """BASELINE config 5 at reduced size: two-style mixing (optex.py:97-101,193-206) over relu3_1..relu1_1 with PCA,
+    hist_mode cdf — the un-rotated hist_match calls of mix_style_features go through the same boundary"""
+    from optimaltextures_amd.driver import OptimalTexture
+    tex = OptimalTexture(size=512, iters=60, passes=2, hist_mode="cdf", mixing_alpha=0.5, layers=(3, 2, 1)).to(dev).eval()
+    a, b = _smooth_image(256, 320, 5).to(dev), _smooth_image(256, 320, 6).to(dev)
+    tex.rng = np.random.RandomState(8)
+    torch.manual_seed(9)
+    with torch.inference_mode():
+        out = tex.forward(torch.rand(1, 3, 512, 512, device=dev), [a, b])
+    assert out.shape == (1, 3, 512, 512) and bool(torch.isfinite(out).all())
+    assert 0.0 < float(out.std()) < 1.0
