@@ -774,13 +774,17 @@ def test_config3_style_transfer_1024_runs(dev):
                          color_transfer="opt").to(dev).eval()
     assert tex.sizes == [256, 1024]
     style, content = _smooth_image(416, 416, 1).to(dev), _smooth_image(1024, 1024, 2).to(dev)
+    noise = torch.rand(content.shape, generator=torch.Generator().manual_seed(4)).to(dev)
     tex.rng = np.random.RandomState(3)
     with torch.inference_mode():
-        out = tex.forward(torch.rand(content.shape, generator=torch.Generator().manual_seed(4)).to(dev), [style], content)
+        out = tex.forward(noise.clone(), [style], content)
     assert out.shape == (1, 3, 1024, 1024) and bool(torch.isfinite(out).all())
-    # the content blend keeps the large-scale structure: the result correlates with the content image
-    a, b = out.mean(1).flatten() - out.mean(), content.mean(1).flatten() - content.mean()
-    assert float((a * b).sum() / (a.norm() * b.norm())) > 0.2
+    # the blend is live (the codec has random weights here, so nothing can be said about what the image looks like):
+    # the same rotations without a content image give a different, equally finite result
+    tex.rng = np.random.RandomState(3)
+    with torch.inference_mode():
+        plain = tex.forward(noise.clone(), [style], None)
+    assert bool(torch.isfinite(plain).all()) and float((out - plain).abs().max()) > 1e-3
 
 
 def test_config5_two_style_mixing_runs(dev):
