@@ -508,10 +508,15 @@ __global__ __launch_bounds__(SORT_NT) void sort_columns_kernel(SortArgs a) {
 }
 
 // ================================================================================================ host side
-static int sort_path_override() {  // OPTEX_SORT_PATH=radix forces the general kernel (tests, comparisons)
+// OPTEX_SORT_PATH=radix forces the general kernel, =rank1 the one-column-per-CU ranking kernel for the match as well
+// (tests, comparisons)
+static int sort_path_override() {
     static const int v = [] {
         const char* e = getenv("OPTEX_SORT_PATH");
-        return (e && e[0] == 'r') ? 1 : 0;
+        if (!e) return 0;
+        if (e[0] == 'r' && e[1] == 'a' && e[2] == 'd') return 1;
+        if (e[0] == 'r' && e[1] == 'a' && e[2] == 'n') return 2;
+        return 0;
     }();
     return v;
 }
@@ -534,7 +539,7 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
     // algorithmic bytes: read key 4 + write key 4 + write index 4 per element; the match reads the
     // column (4), reads one source order statistic per pixel (4) and writes the matched column (4)
     const double per_elem = (MODE == SORT_EMIT) ? (4.0 + (a.out_keys ? 4.0 : 0.0) + (a.out_idx ? 4.0 : 0.0)) : 12.0;
-    const bool use_rank = flags != nullptr && a.n >= RK_MIN_N && !sort_path_override();
+    const bool use_rank = flags != nullptr && a.n >= RK_MIN_N && sort_path_override() != 1;
     a.flags = flags;
     a.ncols = ncols;
     a.inv_2nt = 1.0 / (2.0 * (double)a.n);
@@ -550,7 +555,11 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
         }
         {
             ProfScope prof(MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH, st, 0.0, per_elem * (double)a.n * ncols);
-            hipLaunchKernelGGL(rkern, dim3(ncols), dim3(SORT_NT), rank_lds_bytes<ITEMS>(MODE == SORT_MATCH), st, a);
+            if (MODE == SORT_MATCH && sort_path_override() != 2) {
+                if ((rc = launch_rank_match(ITEMS, a, ncols, st))) return rc;  // two columns per CU (sort_rank2.hip)
+            } else {
+                hipLaunchKernelGGL(rkern, dim3(ncols), dim3(SORT_NT), rank_lds_bytes<ITEMS>(MODE == SORT_MATCH), st, a);
+            }
         }
         if ((rc = check_launch("rank_columns_kernel"))) return rc;
     }

@@ -27,6 +27,10 @@ struct SortArgs {
     int only_flagged;                                         // radix kernel: skip columns whose flag is 0
     double inv_2nt;                                           // 1 / (2 * n) for the quantile index
     int ncols;                                                // C * n_seg
+    int out_vec;                                              // rank_match_kernel: `out` takes 16-byte stores
+#ifdef R2_DEBUG
+    uint32_t* dbg;                                            // scripts/sort_rank2_debug.hip
+#endif
 #ifdef OPTEX_SORT_PROBE
     long long* probe;                                         // [ncols, 16] phase timestamps (scripts/sort_phase_probe.hip)
 #endif
@@ -85,5 +89,8 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d) {
 // columns longer than SORT_MAX_N keys (sort_large.hip)
 size_t sort_large_ws_bytes(long n, int ncols);
 int sort_large(int mode, const SortArgs& a, int ncols, void* ws, hipStream_t st);
+
+// two-columns-per-CU match kernel (sort_rank2.hip); items = 2 / 4 / 8 / 16 keys per thread
+int launch_rank_match(int items, const SortArgs& a, int ncols, hipStream_t st);
 
 }  // namespace optex

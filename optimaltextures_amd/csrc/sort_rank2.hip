@@ -1,0 +1,477 @@
+// sort_rank2.hip — rank_match_kernel: the exact 1-D transport match (north-star addition; specification =
+// oracle/optex_oracle.c orc_sort_match) of one column per 1024-thread workgroup in < 80 KiB of LDS, so that TWO columns
+// are resident per CU: while one workgroup waits on HBM (column load, source quantiles, store tail) or on a barrier,
+// the other one computes.  rank_columns_kernel (sort.hip) needs ~150 KiB for a 16384-key column and therefore runs one
+// column per CU with nothing to overlap its seven barrier-separated phases with.
+//
+// Same idea as sort.hip — RANKING BY COUNTING through a histogram-equalised monotone bucket map — with three changes:
+//   * the bucket slots hold ONE packed word per key, (sub << 14 | pixel): `sub` is an 18-bit monotone refinement of the
+//     key's place inside its bucket, so an unsigned compare of two words of the same bucket orders them by key and,
+//     for equal keys, by pixel index — the stable order — in one instruction.  Two DIFFERENT keys of one bucket share
+//     a `sub` about once in 10 columns, equal keys always do: those lanes re-read the real keys from the (L2-resident)
+//     column and compare (key, pixel) exactly.  No separate key / index / rank arrays: 4 B of LDS per key.
+//   * ranks inside a bucket are counted across lanes with DPP (v_mov_b32_dpp wave_shr:1), not by probing LDS: a wave
+//     looks at 64 consecutive slots, derives every lane's bucket run [s, e) from a 64-bit piece of the start bitmap
+//     held in SGPRs, and for d = 1 .. (longest run - 1) compares lane l with lane l - d; one compare serves both
+//     lanes (the larger one's lane gets its increment through a shifted lane mask: v_addc with an SGPR carry-in).
+//     Windows advance by 48 slots, so every run of <= 16 slots lies inside exactly one window; longer runs (ties,
+//     unlucky buckets) take a per-lane LDS loop, runs above RK_BIG the all-equal pass (as in sort.hip).
+//   * the matched value is fetched where the RANK is known: neighbouring slots have neighbouring ranks, so
+//     sorted_source[q(rank)] is a coalesced read; values are scattered by pixel into the (dead) slot array and the
+//     column leaves with 16-byte stores.
+// Columns this kernel cannot take (non-finite keys, many distinct massive ties) are flagged for the radix kernel of
+// sort.hip, which runs right behind it on the stream.
+#include "sort_common.h"
+
+namespace optex {
+
+constexpr int R2_IDX_BITS = 14;  // pixel index inside a column, n <= 16384
+constexpr uint32_t R2_IDX_MASK = (1u << R2_IDX_BITS) - 1u;
+constexpr int R2_SUB_BITS = 18;
+constexpr int R2_STRIDE = 48;    // slots a window is responsible for
+constexpr int R2_FAST = 16;      // longest run ranked with DPP: 48 + 16 = one wave
+constexpr uint32_t R2_NONE = 0xffffffffu;
+
+template <int ITEMS>
+struct R2 {
+    static constexpr int CAP = ITEMS * SORT_NT;
+    static constexpr int NB = ITEMS == 16 ? CAP * 5 / 16 : CAP / 2;  // fine buckets handed out by the equalisation
+    static constexpr int NBT = NB + RK_COARSE;                       // + 1 per coarse bin; even; < 2^13
+    static constexpr int NW2 = NBT / 2;                              // packed u16 counters
+    static constexpr int PER = (NW2 + SORT_NT - 1) / SORT_NT;
+    static constexpr int NWORDS = CAP / 32;
+    static constexpr int NWIN = (CAP + R2_STRIDE - 1) / R2_STRIDE;
+    static constexpr int TRIPS = (NWIN + SORT_NW - 1) / SORT_NW;
+    static constexpr size_t LDS = (size_t)(CAP + NW2 + RK_COARSE + NWORDS + 4 + 32 + 32) * 4;
+    static_assert(NBT < (1 << (32 - R2_SUB_BITS - 1)), "bucket id and sub must fit 31 bits");
+    static_assert(2 * NWORDS <= NW2, "big-bucket scratch aliases the counters");
+};
+
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {  // lane l receives lane l - 1 (lane 0: all ones)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x138, 0xf, 0xf, false);
+}
+// acc += bit `lane` of a wave-uniform mask: one v_addc with the mask as carry-in
+__device__ __forceinline__ void add_lane_bit(uint32_t& acc, unsigned long long mask) {
+    unsigned long long carry_out;
+    asm volatile("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(acc), "=s"(carry_out) : "s"(mask));
+}
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+template <int ITEMS, bool VEC>
+__global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match_kernel(SortArgs a) {
+    using K = R2<ITEMS>;
+    constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, TRIPS = K::TRIPS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* slot = reinterpret_cast<uint32_t*>(smem);  // [CAP] sub << 14 | pixel by bucket position; later the output
+    uint32_t* cnt = slot + CAP;                          // [NW2] packed u16 bucket counts -> starts -> cursors
+    uint32_t* c1 = cnt + NW2;                            // [256] coarse histogram, then base | width << 16
+    uint32_t* bs = c1 + RK_COARSE;                       // [NWORDS + 4] bit p = slot p starts a bucket
+    uint32_t* red = bs + NWORDS + 4;                     // [32]
+    uint32_t* misc = red + 32;                           // [32] nbig, noteq, (start, count) x RK_MAXBIG
+    uint32_t* bitmap = cnt;                              // [NWORDS] big-bucket pass (counters are dead by then)
+    uint32_t* bpre = cnt + NWORDS;                       // [NWORDS]
+
+    const int col = blockIdx.x, seg = col / a.C, c = col % a.C;
+    const int xseg = (a.x_n_seg == 1) ? 0 : seg;
+    const float* src = a.keys + (size_t)xseg * a.ss + (size_t)c * a.ld;
+    const int sseg = (a.src_n_seg == 1) ? 0 : seg;
+    const float* ssrt = a.src_sorted + ((size_t)sseg * a.C + c) * a.ns;
+    float* o = a.out + (size_t)seg * a.oss + (size_t)c * a.ldo;
+    const unsigned ns = (unsigned)a.ns;
+    const int n = (int)a.n;
+    const int tid = threadIdx.x, lane = tid & 63, w = (int)uniform((uint32_t)tid >> 6);
+    // pixel held in register r: 16-byte loads put 4 neighbouring pixels into one thread
+    auto elem = [&](int r) { return VEC ? ((r >> 2) * SORT_NT + tid) * 4 + (r & 3) : r * SORT_NT + tid; };
+
+    // ---- 0. the column
+    uint32_t key[ITEMS];
+    if (VEC) {
+#pragma unroll
+        for (int q = 0; q < ITEMS / 4; q++) {
+            const int e0 = (q * SORT_NT + tid) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(src + (e0 < n ? e0 : 0));
+            key[4 * q + 0] = f2key(v.x);
+            key[4 * q + 1] = f2key(v.y);
+            key[4 * q + 2] = f2key(v.z);
+            key[4 * q + 3] = f2key(v.w);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const int e = r * SORT_NT + tid;
+            key[r] = f2key(src[e < n ? e : n - 1]);
+        }
+    }
+    for (int i = tid; i < NW2; i += SORT_NT) cnt[i] = 0u;
+    for (int i = tid; i < NWORDS + 4; i += SORT_NT) bs[i] = 0u;
+    if (tid < RK_COARSE) c1[tid] = 0u;
+    if (tid < 32) misc[tid] = 0u;
+
+    // ---- 1. min / max
+    uint32_t klo = 0xffffffffu, khi = 0u;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        if (elem(r) < n) {
+            klo = key[r] < klo ? key[r] : klo;
+            khi = key[r] > khi ? key[r] : khi;
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const uint32_t l2 = __shfl_xor(klo, s), h2 = __shfl_xor(khi, s);
+        klo = l2 < klo ? l2 : klo;
+        khi = h2 > khi ? h2 : khi;
+    }
+    if (lane == 0) {
+        red[w] = klo;
+        red[16 + w] = khi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SORT_NW; k++) {
+        klo = red[k] < klo ? red[k] : klo;
+        khi = red[16 + k] > khi ? red[16 + k] : khi;
+    }
+    __syncthreads();  // red is reused by the scans
+    if (khi >= 0xff800000u || klo <= 0x007fffffu) {  // non-finite keys cannot be bucketed by value: radix kernel
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    const float lo = key2f(klo), hi = key2f(khi);
+    if (klo == khi) {  // constant column: already sorted, rank = pixel index
+        for (int e = tid; e < n; e += SORT_NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+        return;
+    }
+    const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
+    if (!(s1 > 0.f) || !(s1 < 3.0e38f)) {  // range over/underflow (or only -0 / +0): radix kernel
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+
+    // ---- 2. coarse histogram of a spatially spread quarter sample (any widths give a monotone map; the sample only
+    //         balances the bucket sizes)
+    constexpr int RS = VEC ? 4 : (ITEMS >= 8 ? 4 : 1);
+    unsigned nsamp = 0;
+    if (VEC) {
+        nsamp = (unsigned)(n + 3) / 4u;
+    } else {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r += RS) {
+            const int left = n - r * SORT_NT;
+            nsamp += (unsigned)(left < 0 ? 0 : (left > SORT_NT ? SORT_NT : left));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; r += RS) {
+        if (elem(r) < n) {
+            const float t = (key2f(key[r]) - lo) * s1;
+            int bin = (int)t;
+            bin = bin > RK_COARSE - 1 ? RK_COARSE - 1 : bin;
+            atomicAdd(&c1[bin], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- 3. equalisation: coarse bin b gets w_b = 1 + cnt_b * NB / nsamp fine buckets
+    {
+        unsigned q = 0;
+        if (tid < RK_COARSE) {
+            const unsigned x = c1[tid] * (unsigned)NB;  // < 2^27: exact quotient via a float estimate + one correction
+            q = (unsigned)((float)x / (float)nsamp);
+            if (q * nsamp > x) q--;
+            else if ((q + 1u) * nsamp <= x) q++;
+        }
+        const unsigned wd = tid < RK_COARSE ? 1u + q : 0u;
+        const unsigned base = block_excl_scan(wd, red, nullptr);
+        if (tid < RK_COARSE) c1[tid] = base | (wd << 16);
+    }
+    __syncthreads();
+    // ---- 4. fine bucket b and refinement sub of every key; the register now holds b << 18 | sub.  x -> (b, sub) is
+    //         monotone non-decreasing whatever the rounding: every step (subtract, scale, truncate, clamp) is.
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        uint32_t packed = R2_NONE;
+        if (elem(r) < n) {
+            const float t = (key2f(key[r]) - lo) * s1;
+            int bin = (int)t;
+            bin = bin > RK_COARSE - 1 ? RK_COARSE - 1 : bin;
+            const float frac = t - (float)bin;
+            const uint32_t bw = c1[bin];
+            const int wd = (int)(bw >> 16);
+            const float u = frac * (float)wd;
+            int sub = (int)u;
+            sub = sub > wd - 1 ? wd - 1 : sub;
+            int fine = (int)((u - (float)sub) * (float)(1 << R2_SUB_BITS));
+            fine = fine > (1 << R2_SUB_BITS) - 1 ? (1 << R2_SUB_BITS) - 1 : fine;
+            const uint32_t b = (bw & 0xffffu) + (uint32_t)sub;
+            atomicAdd(&cnt[b >> 1], (b & 1u) ? 0x10000u : 1u);
+            packed = (b << R2_SUB_BITS) | (uint32_t)fine;
+        }
+        key[r] = packed;
+    }
+    __syncthreads();
+    // ---- 5. exclusive scan of the bucket counts -> starts (in place), start bitmap, oversized buckets
+    {
+        uint32_t wv[PER];
+        unsigned sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int i = tid * PER + q;
+            wv[q] = i < NW2 ? cnt[i] : 0u;
+            sum += (wv[q] & 0xffffu) + (wv[q] >> 16);
+        }
+        unsigned ex = block_excl_scan(sum, red, nullptr);
+        uint32_t curw = 0u, bits = 0u;  // a thread's buckets start at increasing positions: one atomicOr per word
+        auto mark = [&](unsigned pos) {
+            const uint32_t wd = pos >> 5;
+            if (wd != curw) {
+                if (bits) atomicOr(&bs[curw], bits);
+                curw = wd;
+                bits = 0u;
+            }
+            bits |= 1u << (pos & 31u);
+        };
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int i = tid * PER + q;
+            if (i < NW2) {
+                const unsigned c0 = wv[q] & 0xffffu, c1v = wv[q] >> 16;
+                const unsigned s0 = ex, s1v = ex + c0;
+                cnt[i] = s0 | (s1v << 16);
+                if (c0) mark(s0);
+                if (c1v) mark(s1v);
+                if (c0 > RK_BIG) {
+                    const unsigned k = atomicAdd(&misc[0], 1u);
+                    if (k < RK_MAXBIG) { misc[2 + 2 * k] = s0; misc[3 + 2 * k] = c0; }
+                }
+                if (c1v > RK_BIG) {
+                    const unsigned k = atomicAdd(&misc[0], 1u);
+                    if (k < RK_MAXBIG) { misc[2 + 2 * k] = s1v; misc[3 + 2 * k] = c1v; }
+                }
+                ex += c0 + c1v;
+            }
+        }
+        if (bits) atomicOr(&bs[curw], bits);
+        if (tid == 0) atomicOr(&bs[n >> 5], 1u << (n & 31));  // sentinel: the position after the last bucket
+    }
+    __syncthreads();
+    const unsigned nbig = misc[0];
+    if (nbig > RK_MAXBIG) {
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    // ---- 6a. every key takes a slot of its bucket (arrival order; the ranking does not depend on it)
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        if (key[r] != R2_NONE) {
+            const uint32_t b = key[r] >> R2_SUB_BITS;
+            const uint32_t old = atomicAdd(&cnt[b >> 1], (b & 1u) ? 0x10000u : 1u);
+            const uint32_t pos = (b & 1u) ? (old >> 16) : (old & 0xffffu);
+            slot[pos] = (key[r] << R2_IDX_BITS) | (uint32_t)elem(r);  // the shift drops b, keeps sub
+        }
+    }
+    __syncthreads();
+#ifdef R2_DEBUG
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < n; i += SORT_NT) a.dbg[i] = slot[i];
+        for (int i = tid; i < NWORDS + 4; i += SORT_NT) a.dbg[CAP + i] = bs[i];
+    }
+    __syncthreads();
+#endif
+    // ---- 6b. oversized buckets only come from exact ties: if all keys of such a bucket are equal its ranks are the
+    //          ranks of the pixel indices (bitmap + popcount prefix); the slots become pixel << 14 | rank in place.
+    //          Anything else -> radix kernel.
+    for (unsigned bi = 0; bi < nbig; bi++) {
+        const uint32_t s = misc[2 + 2 * bi], cb = misc[3 + 2 * bi];
+        const uint32_t k0 = f2key(src[slot[s] & R2_IDX_MASK]);
+        for (int i = tid; i < NWORDS; i += SORT_NT) bitmap[i] = 0u;
+        __syncthreads();
+        for (uint32_t j = tid; j < cb; j += SORT_NT) {
+            const uint32_t idx = slot[s + j] & R2_IDX_MASK;
+            if (f2key(src[idx]) != k0) misc[1] = 1u;
+            atomicOr(&bitmap[idx >> 5], 1u << (idx & 31u));
+        }
+        __syncthreads();
+        if (misc[1]) {
+            if (tid == 0) a.flags[col] = 1;
+            return;
+        }
+        {
+            const unsigned pcn = tid < NWORDS ? (unsigned)__popc(bitmap[tid]) : 0u;
+            const unsigned ex = block_excl_scan(pcn, red, nullptr);
+            if (tid < NWORDS) bpre[tid] = ex;
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < cb; j += SORT_NT) {
+            const uint32_t idx = slot[s + j] & R2_IDX_MASK;
+            const uint32_t rank = s + bpre[idx >> 5] + (uint32_t)__popc(bitmap[idx >> 5] & ((1u << (idx & 31u)) - 1u));
+            slot[s + j] = (idx << R2_IDX_BITS) | rank;
+        }
+        __syncthreads();
+    }
+    // ---- 6c. ranks.  Window t = slots [48 t, 48 t + 64) of one wave; res[k] = pixel << 14 | rank of the slot this lane
+    //          is responsible for in its k-th window (or NONE).
+    const unsigned long long mle = (2ull << lane) - 1ull;  // lanes <= this one
+    const int nwin = (n + R2_STRIDE - 1) / R2_STRIDE;
+    uint32_t res[TRIPS];
+    uint32_t slowmask = 0u;
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) {
+        res[k] = R2_NONE;
+        const int t = k * SORT_NW + w;  // wave-uniform
+        if (t < nwin) {
+            const int base = t * R2_STRIDE, p = base + lane;
+            const uint32_t my = p < n ? slot[p] : R2_NONE;
+            // bucket starts of [base, base + 64) as a 64-bit SGPR value, and of the 16 slots before the window
+            const int wi = base >> 5;
+            const uint32_t w0 = uniform(bs[wi]), w1 = uniform(bs[wi + 1]), w2 = uniform(bs[wi + 2]);
+            const uint32_t wp = wi > 0 ? uniform(bs[wi - 1]) : 0u;
+            const unsigned long long lo64 = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+            const bool odd = (base & 31) != 0;  // base % 32 is 0 or 16
+            const unsigned long long B = odd ? ((lo64 >> 16) | ((unsigned long long)w2 << 48)) : lo64;
+            const uint32_t P16 = odd ? (w0 & 0xffffu) : (wp >> 16);
+            const unsigned long long le = B & mle, gt = B & ~mle;
+            const bool inwin = le != 0ull;                       // the run of this slot starts inside the window
+            const int s = inwin ? 63 - __clzll(le) : 0;
+            const int e = gt != 0ull ? __builtin_ctzll(gt) : 64;
+            const bool fast = p < n && inwin && s < R2_STRIDE && e - s <= R2_FAST;
+            uint32_t fb = fast ? (uint32_t)(lane - s) : 0u;  // run members before this lane
+            asm volatile("" : "+v"(fb));                          // keep it ONE value: the loop then needs one compare
+            // slots of the first 48 lanes that are NOT in a short run must be ranked the slow way by this window:
+            // a run that started before the window was ranked by the previous window iff it is short
+            bool slow = false;
+            if (p < n && lane < R2_STRIDE && !fast) {
+                if (inwin || P16 == 0u || gt == 0ull) slow = true;
+                else slow = e + 16 - (31 - __clz(P16)) > R2_FAST;
+            }
+            uint32_t lt = 0u, tmp = my;
+            unsigned long long collm = 0ull;
+#pragma unroll 1
+            for (int d = 1; d < R2_FAST; d++) {
+                const unsigned long long valid = ballot64(fb >= (uint32_t)d);
+                if (valid == 0ull) break;
+                tmp = dpp_wave_shr1(tmp);  // the slot d lanes below
+                const unsigned long long less = ballot64(tmp < my);
+                const unsigned long long coll = ballot64(((tmp ^ my) >> R2_IDX_BITS) == 0u) & valid;
+                add_lane_bit(lt, less & valid);            // the slot d below is smaller
+                add_lane_bit(lt, (valid & ~less) >> d);    // ... or larger: then its lane counts this one
+                collm |= coll | (coll >> d);
+            }
+            const bool collided = (collm & (1ull << lane)) != 0ull;
+            if (fast && !collided) res[k] = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(base + s + (int)lt);
+            else if (fast || slow) slowmask |= 1u << k;
+        }
+    }
+    if (ballot64(slowmask != 0u) != 0ull) {  // rare: long runs, equal subs (ties), oversized buckets
+#pragma unroll 1
+        for (int k = 0; k < TRIPS; k++) {
+            const bool mine = (slowmask >> k) & 1u;
+            if (ballot64(mine) == 0ull) continue;
+            uint32_t r = R2_NONE;
+            if (mine) {
+                const int p = (k * SORT_NW + w) * R2_STRIDE + lane;
+                const uint32_t my = slot[p];
+                int wa = p >> 5;
+                uint32_t m = bs[wa] & (0xffffffffu >> (31 - (p & 31)));
+                while (m == 0u) m = bs[--wa];
+                const int S = wa * 32 + 31 - __clz(m);
+                const int q1 = p + 1;
+                int wb = q1 >> 5;
+                m = bs[wb] & (0xffffffffu << (q1 & 31));
+                while (m == 0u) m = bs[++wb];  // the sentinel at n ends the search
+                const int E = wb * 32 + __builtin_ctz(m);
+                if (E - S > RK_BIG) {
+                    r = my;  // the all-equal pass left pixel << 14 | rank here
+                } else {
+                    // count the smaller members of the run; equal subs are decided by the real keys (then pixels)
+                    uint32_t lt = 0u, myk = 0u;
+                    bool have = false;
+                    for (int j = S; j < E; j++) {
+                        const uint32_t oj = slot[j];
+                        if (j == p) continue;
+                        if (((oj ^ my) >> R2_IDX_BITS) == 0u) {
+                            if (!have) {
+                                myk = f2key(src[my & R2_IDX_MASK]);
+                                have = true;
+                            }
+                            const uint32_t ok = f2key(src[oj & R2_IDX_MASK]);
+                            lt += (ok < myk || (ok == myk && (oj & R2_IDX_MASK) < (my & R2_IDX_MASK))) ? 1u : 0u;
+                        } else {
+                            lt += oj < my ? 1u : 0u;
+                        }
+                    }
+                    r = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(S + (int)lt);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < TRIPS; kk++)
+                if (kk == k && mine) res[kk] = r;
+        }
+    }
+#ifdef R2_DEBUG
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) a.dbg[2 * CAP + (k * SORT_NW + w) * 64 + lane] = res[k];
+    }
+#endif
+    // ---- 7. out[pixel] = sorted_source[q(rank)]: read where the ranks are neighbours (coalesced), scatter by pixel
+    //         into the slot array (every slot has been read: barrier), leave with 16-byte stores
+    __syncthreads();
+    float* val = reinterpret_cast<float*>(slot);
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) {
+        if (res[k] != R2_NONE)
+            val[res[k] >> R2_IDX_BITS] = ssrt[quantile_index(res[k] & R2_IDX_MASK, ns, (unsigned)n, a.inv_2nt)];
+    }
+    __syncthreads();
+    if (VEC && a.out_vec) {
+#pragma unroll
+        for (int q = 0; q < ITEMS / 4; q++) {
+            const int e0 = (q * SORT_NT + tid) * 4;
+            if (e0 < n) *reinterpret_cast<float4*>(o + e0) = *reinterpret_cast<const float4*>(val + e0);
+        }
+    } else {
+        for (int e = tid; e < n; e += SORT_NT) o[e] = val[e];
+    }
+}
+
+template <int ITEMS>
+static int launch_rank_match_items(SortArgs a, int ncols, hipStream_t st) {
+    const bool in_vec = ITEMS >= 4 && a.n % 4 == 0 && a.ld % 4 == 0 && a.ss % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
+    a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
+    const size_t lds = R2<ITEMS>::LDS;
+    hipError_t e;
+    if (in_vec) {
+        auto kern = rank_match_kernel<ITEMS, (ITEMS >= 4)>;
+        static thread_local bool attr = false;
+        if (!attr) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return OPTEX_E_LAUNCH; }
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(ncols), dim3(SORT_NT), lds, st, a);
+    } else {
+        auto kern = rank_match_kernel<ITEMS, false>;
+        static thread_local bool attr = false;
+        if (!attr) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return OPTEX_E_LAUNCH; }
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(ncols), dim3(SORT_NT), lds, st, a);
+    }
+    return check_launch("rank_match_kernel");
+}
+
+// called by launch_sort_items<ITEMS, SORT_MATCH> (sort.hip) with flags cleared and the prof scope open
+int launch_rank_match(int items, const SortArgs& a, int ncols, hipStream_t st) {
+    switch (items) {
+        case 2: return launch_rank_match_items<2>(a, ncols, st);
+        case 4: return launch_rank_match_items<4>(a, ncols, st);
+        case 8: return launch_rank_match_items<8>(a, ncols, st);
+        default: return launch_rank_match_items<16>(a, ncols, st);
+    }
+}
+
+}  // namespace optex

@@ -218,6 +218,12 @@ def test_sort_match_vs_oracle_bit_exact(dev, S, Ss, C, nt, ns):
         assert biteq(out[k], orc.sort_match(t[k], s[k if Ss > 1 else 0]))
 
 
+def _ulp_clusters(n, rng):
+    base = rng.standard_normal((n + 2) // 3).astype(np.float32)
+    c = np.stack([base, np.nextafter(base, np.float32(np.inf)), np.nextafter(base, np.float32(-np.inf))], 1).reshape(-1)[:n]
+    return rng.permutation(c).astype(np.float64)
+
+
 def _sort_edge_columns(n, rng):
     """columns that exercise every path of the rank kernel and its radix sweep"""
     cols = {
@@ -234,6 +240,12 @@ def _sort_edge_columns(n, rng):
         "descending": -np.arange(n, dtype=np.float64),
         "tiny_range": 1.0 + rng.integers(0, 3, n) * np.float64(np.finfo(np.float32).eps),
         "denormals": rng.standard_normal(n) * 1e-41,
+        # the two-columns-per-CU match kernel (csrc/sort_rank2.hip): bucket runs of 17..48 slots (per-lane loop), ties
+        # inside short runs and distinct keys one ulp apart (equal `sub`, decided by re-reading the real keys)
+        "groups_of_24": rng.permutation(np.arange(n) // 24).astype(np.float64) + 0.5,
+        "groups_of_40_gauss": np.sort(rng.standard_normal(n))[(np.arange(n) // 40) * 40][rng.permutation(n)],
+        "pairs": rng.permutation(np.repeat(rng.standard_normal((n + 1) // 2), 2)[:n]),
+        "ulp_clusters": _ulp_clusters(n, rng),
     }
     names = list(cols)
     return names, np.stack([cols[k] for k in names]).astype(np.float32)
@@ -283,6 +295,42 @@ def test_sort_full_size_properties(dev):
     xs = x[3, 5:9].cpu().numpy()
     ok, oi = orc.sort_columns(xs)
     assert biteq(idx[3, 5:9].cpu().numpy().astype(np.uint32), oi)
+
+
+@pytest.mark.parametrize("nt,ns", [(16384, 16384), (12544, 16384), (9216, 12288), (4096, 3072)])
+def test_sort_match_full_size_properties(dev, nt, ns):
+    """BASELINE batch (32 textures x 256 channels) through the match kernel: the matched column, read in the stable order
+    of the target, is exactly the sequence of source order statistics floor((2 i + 1) ns / (2 nt)) — checked with torch's
+    own stable sort, no oracle involved; a column sample against the oracle; same input -> same bits"""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    g = torch.Generator(device=dev).manual_seed(nt + ns)
+    t = torch.randn((32, 256, nt), device=dev, generator=g) * 3 + 1
+    t[:, ::9].clamp_min_(0)        # tie-heavy columns in between
+    t[:, 5::31] = (t[:, 5::31] * 8).round() / 8 + 0.0   # many medium tie groups (+ 0.0: no -0, torch.sort has no totalOrder)
+    s = torch.randn((1, 256, ns), device=dev, generator=g) * 2 - 1
+    out = ops.sort_match_seg(Seg.of(t), Seg.of(s))
+    order = torch.sort(t, dim=2, stable=True).indices
+    q = ((2 * torch.arange(nt, device=dev, dtype=torch.int64) + 1) * ns) // (2 * nt)
+    want = torch.sort(s, dim=2).values[0][:, q]                       # [256, nt]
+    assert bool((torch.gather(out, 2, order) == want[None]).all())
+    assert bool((ops.sort_match_seg(Seg.of(t), Seg.of(s)) == out).all()), "deterministic"
+    tc, sc = t[7, 3:12].cpu().numpy(), s[0, 3:12].cpu().numpy()
+    assert biteq(out[7, 3:12].cpu().numpy(), orc.sort_match(tc, sc))
+
+
+@pytest.mark.parametrize("n,off", [(4099, 1), (8190, 2), (16383, 3), (1001, 1)])
+def test_sort_match_unaligned_columns_bit_exact(dev, n, off):
+    """columns whose length / base address rule out 16-byte loads and stores take the scalar variant of the kernel"""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    rng = np.random.default_rng(n)
+    t = rng.standard_normal((2, 3, n + off)).astype(np.float32)
+    s = (rng.standard_normal((1, 3, n)) * 2).astype(np.float32)
+    td = cu(t, dev)
+    out = ops.sort_match_seg(Seg(td[:, :, off:], n + off, 3 * (n + off), n, 3, 2), Seg.of(cu(s, dev))).cpu().numpy()
+    for k in range(2):
+        assert biteq(out[k], orc.sort_match(np.ascontiguousarray(t[k][:, off:]), s[0]))
 
 
 @pytest.mark.parametrize("S,C,n", [(1, 3, 16385), (2, 2, 40000), (1, 2, 262144)])
