@@ -31,6 +31,7 @@ constexpr int R2_SUB_BITS = 18;
 constexpr int R2_STRIDE = 48;    // slots a window is responsible for
 constexpr int R2_FAST = 16;      // longest run ranked with DPP: 48 + 16 = one wave
 constexpr uint32_t R2_NONE = 0xffffffffu;
+constexpr int R2_QCAP = 256;     // slots per column that may need the exact path before the column goes to the radix kernel
 
 template <int ITEMS>
 struct R2 {
@@ -42,7 +43,7 @@ struct R2 {
     static constexpr int NWORDS = CAP / 32;
     static constexpr int NWIN = (CAP + R2_STRIDE - 1) / R2_STRIDE;
     static constexpr int TRIPS = (NWIN + SORT_NW - 1) / SORT_NW;
-    static constexpr size_t LDS = (size_t)(CAP + NW2 + RK_COARSE + NWORDS + 4 + 32 + 32) * 4;
+    static constexpr size_t LDS = (size_t)(CAP + NW2 + RK_COARSE + NWORDS + 4 + 32 + 32 + R2_QCAP) * 4;
     static_assert(NBT < (1 << (32 - R2_SUB_BITS - 1)), "bucket id and sub must fit 31 bits");
     static_assert(2 * NWORDS <= NW2, "big-bucket scratch aliases the counters");
 };
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     uint32_t* c1 = cnt + NW2;                            // [256] coarse histogram, then base | width << 16
     uint32_t* bs = c1 + RK_COARSE;                       // [NWORDS + 4] bit p = slot p starts a bucket
     uint32_t* red = bs + NWORDS + 4;                     // [32]
-    uint32_t* misc = red + 32;                           // [32] nbig, noteq, (start, count) x RK_MAXBIG
+    uint32_t* misc = red + 32;                           // [32] nbig, noteq, (start, count) x RK_MAXBIG, [20] queue length
+    uint32_t* queue = misc + 32;                         // [R2_QCAP] slots that need the exact path
     uint32_t* bitmap = cnt;                              // [NWORDS] big-bucket pass (counters are dead by then)
     uint32_t* bpre = cnt + NWORDS;                       // [NWORDS]
 
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // pixel held in register r: 16-byte loads put 4 neighbouring pixels into one thread
     auto elem = [&](int r) { return VEC ? ((r >> 2) * SORT_NT + tid) * 4 + (r & 3) : r * SORT_NT + tid; };
 
+    SORT_PROBE(0);
     // ---- 0. the column
     uint32_t key[ITEMS];
     if (VEC) {
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         return;
     }
 
+    SORT_PROBE(1);
     // ---- 2. coarse histogram of a spatially spread quarter sample (any widths give a monotone map; the sample only
     //         balances the bucket sizes)
     constexpr int RS = VEC ? 4 : (ITEMS >= 8 ? 4 : 1);
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
     }
     __syncthreads();
+    SORT_PROBE(2);
     // ---- 3. equalisation: coarse bin b gets w_b = 1 + cnt_b * NB / nsamp fine buckets
     {
         unsigned q = 0;
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (tid < RK_COARSE) c1[tid] = base | (wd << 16);
     }
     __syncthreads();
+    SORT_PROBE(3);
     // ---- 4. fine bucket b and refinement sub of every key; the register now holds b << 18 | sub.  x -> (b, sub) is
     //         monotone non-decreasing whatever the rounding: every step (subtract, scale, truncate, clamp) is.
 #pragma unroll
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         key[r] = packed;
     }
     __syncthreads();
+    SORT_PROBE(4);
     // ---- 5. exclusive scan of the bucket counts -> starts (in place), start bitmap, oversized buckets
     {
         uint32_t wv[PER];
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (tid == 0) a.flags[col] = 1;
         return;
     }
+    SORT_PROBE(5);
     // ---- 6a. every key takes a slot of its bucket (arrival order; the ranking does not depend on it)
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -309,12 +317,12 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
         __syncthreads();
     }
+    SORT_PROBE(6);
     // ---- 6c. ranks.  Window t = slots [48 t, 48 t + 64) of one wave; res[k] = pixel << 14 | rank of the slot this lane
     //          is responsible for in its k-th window (or NONE).
     const unsigned long long mle = (2ull << lane) - 1ull;  // lanes <= this one
     const int nwin = (n + R2_STRIDE - 1) / R2_STRIDE;
     uint32_t res[TRIPS];
-    uint32_t slowmask = 0u;
 #pragma unroll
     for (int k = 0; k < TRIPS; k++) {
         res[k] = R2_NONE;
@@ -335,8 +343,6 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const int s = inwin ? 63 - __clzll(le) : 0;
             const int e = gt != 0ull ? __builtin_ctzll(gt) : 64;
             const bool fast = p < n && inwin && s < R2_STRIDE && e - s <= R2_FAST;
-            uint32_t fb = fast ? (uint32_t)(lane - s) : 0u;  // run members before this lane
-            asm volatile("" : "+v"(fb));                          // keep it ONE value: the loop then needs one compare
             // slots of the first 48 lanes that are NOT in a short run must be ranked the slow way by this window:
             // a run that started before the window was ranked by the previous window iff it is short
             bool slow = false;
@@ -344,69 +350,74 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 if (inwin || P16 == 0u || gt == 0ull) slow = true;
                 else slow = e + 16 - (31 - __clz(P16)) > R2_FAST;
             }
-            uint32_t lt = 0u, tmp = my;
-            unsigned long long collm = 0ull;
+            // lanes whose run has >= d members below them, d = 1, 2, ...: V_d = V_{d-1} & (N << (d - 1)) with N = the
+            // lanes that do not start a run — scalar work, independent of the vector compares
+            const unsigned long long N = ~B;
+            unsigned long long Vd = N & ballot64(fast);
+            uint32_t lt = 0u, tmp = my, nearest = 0xffffffffu;
 #pragma unroll 1
-            for (int d = 1; d < R2_FAST; d++) {
-                const unsigned long long valid = ballot64(fb >= (uint32_t)d);
-                if (valid == 0ull) break;
+            for (int d = 1; d < R2_FAST && Vd != 0ull; d++) {
                 tmp = dpp_wave_shr1(tmp);  // the slot d lanes below
                 const unsigned long long less = ballot64(tmp < my);
-                const unsigned long long coll = ballot64(((tmp ^ my) >> R2_IDX_BITS) == 0u) & valid;
-                add_lane_bit(lt, less & valid);            // the slot d below is smaller
-                add_lane_bit(lt, (valid & ~less) >> d);    // ... or larger: then its lane counts this one
-                collm |= coll | (coll >> d);
+                const uint32_t x = tmp ^ my;
+                nearest = x < nearest ? x : nearest;       // equal subs show up as a difference below 2^14
+                add_lane_bit(lt, less & Vd);               // the slot d below is smaller
+                add_lane_bit(lt, (Vd & ~less) >> d);       // ... or larger: then its lane counts this one
+                Vd &= N << d;
             }
-            const bool collided = (collm & (1ull << lane)) != 0ull;
-            if (fast && !collided) res[k] = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(base + s + (int)lt);
-            else if (fast || slow) slowmask |= 1u << k;
-        }
-    }
-    if (ballot64(slowmask != 0u) != 0ull) {  // rare: long runs, equal subs (ties), oversized buckets
-#pragma unroll 1
-        for (int k = 0; k < TRIPS; k++) {
-            const bool mine = (slowmask >> k) & 1u;
-            if (ballot64(mine) == 0ull) continue;
-            uint32_t r = R2_NONE;
-            if (mine) {
-                const int p = (k * SORT_NW + w) * R2_STRIDE + lane;
-                const uint32_t my = slot[p];
-                int wa = p >> 5;
-                uint32_t m = bs[wa] & (0xffffffffu >> (31 - (p & 31)));
-                while (m == 0u) m = bs[--wa];
-                const int S = wa * 32 + 31 - __clz(m);
-                const int q1 = p + 1;
-                int wb = q1 >> 5;
-                m = bs[wb] & (0xffffffffu << (q1 & 31));
-                while (m == 0u) m = bs[++wb];  // the sentinel at n ends the search
-                const int E = wb * 32 + __builtin_ctz(m);
-                if (E - S > RK_BIG) {
-                    r = my;  // the all-equal pass left pixel << 14 | rank here
+            // a pair with equal subs sends its whole run to the exact path (the rare neighbour of another run that
+            // happens to share a sub only costs time)
+            const unsigned long long cm = ballot64(fast && (nearest >> R2_IDX_BITS) == 0u);
+            const bool collided = cm != 0ull && ((cm >> s) & ((1ull << (fast ? e - s : 1)) - 1ull)) != 0ull;
+            if (fast && !collided) {
+                res[k] = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(base + s + (int)lt);
+            } else if (fast || slow) {
+                bool in_big = false;  // the all-equal pass left pixel << 14 | rank in the slots of oversized buckets
+                for (unsigned bi = 0; bi < nbig; bi++) in_big = in_big || ((uint32_t)p - misc[2 + 2 * bi] < misc[3 + 2 * bi]);
+                if (in_big) {
+                    res[k] = my;
                 } else {
-                    // count the smaller members of the run; equal subs are decided by the real keys (then pixels)
-                    uint32_t lt = 0u, myk = 0u;
-                    bool have = false;
-                    for (int j = S; j < E; j++) {
-                        const uint32_t oj = slot[j];
-                        if (j == p) continue;
-                        if (((oj ^ my) >> R2_IDX_BITS) == 0u) {
-                            if (!have) {
-                                myk = f2key(src[my & R2_IDX_MASK]);
-                                have = true;
-                            }
-                            const uint32_t ok = f2key(src[oj & R2_IDX_MASK]);
-                            lt += (ok < myk || (ok == myk && (oj & R2_IDX_MASK) < (my & R2_IDX_MASK))) ? 1u : 0u;
-                        } else {
-                            lt += oj < my ? 1u : 0u;
-                        }
-                    }
-                    r = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(S + (int)lt);
+                    const uint32_t qi = atomicAdd(&misc[20], 1u);
+                    if (qi < (uint32_t)R2_QCAP) queue[qi] = (uint32_t)p;
                 }
             }
-#pragma unroll
-            for (int kk = 0; kk < TRIPS; kk++)
-                if (kk == k && mine) res[kk] = r;
         }
+    }
+    // ---- 6d. the exact path, one queued slot per thread (all at once: their memory latencies overlap): long runs and
+    //          runs in which two slots share a sub (ties, or distinct keys closer than the refinement resolves)
+    __syncthreads();
+    const uint32_t qn = misc[20];
+    if (qn > (uint32_t)R2_QCAP) {  // tie-heavy column: radix kernel
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    uint32_t qres = R2_NONE;
+    if ((uint32_t)tid < qn) {
+        const int p = (int)queue[tid];
+        const uint32_t my = slot[p];
+        int wa = p >> 5;
+        uint32_t m = bs[wa] & (0xffffffffu >> (31 - (p & 31)));
+        while (m == 0u) m = bs[--wa];
+        const int S = wa * 32 + 31 - __clz(m);
+        const int q1 = p + 1;
+        int wb = q1 >> 5;
+        m = bs[wb] & (0xffffffffu << (q1 & 31));
+        while (m == 0u) m = bs[++wb];  // the sentinel at n ends the search
+        const int E = wb * 32 + __builtin_ctz(m);
+        // count the smaller members of the run; equal subs are decided by the real keys (then pixels)
+        const uint32_t myk = f2key(src[my & R2_IDX_MASK]);
+        uint32_t lt = 0u;
+        for (int j = S; j < E; j++) {
+            const uint32_t oj = slot[j];
+            if (j == p) continue;
+            if (((oj ^ my) >> R2_IDX_BITS) == 0u) {
+                const uint32_t ok = f2key(src[oj & R2_IDX_MASK]);
+                lt += (ok < myk || (ok == myk && (oj & R2_IDX_MASK) < (my & R2_IDX_MASK))) ? 1u : 0u;
+            } else {
+                lt += oj < my ? 1u : 0u;
+            }
+        }
+        qres = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(S + (int)lt);
     }
 #ifdef R2_DEBUG
     if (blockIdx.x == 0) {
@@ -414,16 +425,28 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (int k = 0; k < TRIPS; k++) a.dbg[2 * CAP + (k * SORT_NW + w) * 64 + lane] = res[k];
     }
 #endif
+    SORT_PROBE(7);
     // ---- 7. out[pixel] = sorted_source[q(rank)]: read where the ranks are neighbours (coalesced), scatter by pixel
     //         into the slot array (every slot has been read: barrier), leave with 16-byte stores
     __syncthreads();
     float* val = reinterpret_cast<float*>(slot);
+    const float qv = ssrt[quantile_index(qres != R2_NONE ? (qres & R2_IDX_MASK) : 0u, ns, (unsigned)n, a.inv_2nt)];
+    constexpr int FCH = 8;  // loads of a chunk are all in flight before the first LDS write waits for one
 #pragma unroll
-    for (int k = 0; k < TRIPS; k++) {
-        if (res[k] != R2_NONE)
-            val[res[k] >> R2_IDX_BITS] = ssrt[quantile_index(res[k] & R2_IDX_MASK, ns, (unsigned)n, a.inv_2nt)];
+    for (int k0 = 0; k0 < TRIPS; k0 += FCH) {
+        float v[FCH];
+#pragma unroll
+        for (int k = k0; k < k0 + FCH && k < TRIPS; k++) {
+            const uint32_t rank = res[k] != R2_NONE ? (res[k] & R2_IDX_MASK) : 0u;
+            v[k - k0] = ssrt[quantile_index(rank, ns, (unsigned)n, a.inv_2nt)];
+        }
+#pragma unroll
+        for (int k = k0; k < k0 + FCH && k < TRIPS; k++)
+            if (res[k] != R2_NONE) val[res[k] >> R2_IDX_BITS] = v[k - k0];
     }
+    if (qres != R2_NONE) val[qres >> R2_IDX_BITS] = qv;
     __syncthreads();
+    SORT_PROBE(8);
     if (VEC && a.out_vec) {
 #pragma unroll
         for (int q = 0; q < ITEMS / 4; q++) {
@@ -433,6 +456,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     } else {
         for (int e = tid; e < n; e += SORT_NT) o[e] = val[e];
     }
+    SORT_PROBE(9);
 }
 
 template <int ITEMS>
