@@ -4,21 +4,22 @@
 // the other one computes.  rank_columns_kernel (sort.hip) needs ~150 KiB for a 16384-key column and therefore runs one
 // column per CU with nothing to overlap its seven barrier-separated phases with.
 //
-// Same idea as sort.hip — RANKING BY COUNTING through a histogram-equalised monotone bucket map — with three changes:
+// Same idea as sort.hip — RANKING BY COUNTING through a histogram-equalised monotone bucket map — with these changes:
 //   * the bucket slots hold ONE packed word per key, (sub << 14 | pixel): `sub` is an 18-bit monotone refinement of the
 //     key's place inside its bucket, so an unsigned compare of two words of the same bucket orders them by key and,
 //     for equal keys, by pixel index — the stable order — in one instruction.  Two DIFFERENT keys of one bucket share
-//     a `sub` about once in 10 columns, equal keys always do: those lanes re-read the real keys from the (L2-resident)
-//     column and compare (key, pixel) exactly.  No separate key / index / rank arrays: 4 B of LDS per key.
-//   * ranks inside a bucket are counted across lanes with DPP (v_mov_b32_dpp wave_shr:1), not by probing LDS: a wave
-//     looks at 64 consecutive slots, derives every lane's bucket run [s, e) from a 64-bit piece of the start bitmap
-//     held in SGPRs, and for d = 1 .. (longest run - 1) compares lane l with lane l - d; one compare serves both
-//     lanes (the larger one's lane gets its increment through a shifted lane mask: v_addc with an SGPR carry-in).
-//     Windows advance by 48 slots, so every run of <= 16 slots lies inside exactly one window; longer runs (ties,
-//     unlucky buckets) take a per-lane LDS loop, runs above RK_BIG the all-equal pass (as in sort.hip).
+//     a `sub` a dozen times per column (fp32 resolution of the bucket coordinate), equal keys always do: those slots
+//     are queued, and one thread per queued slot re-reads the real keys from the (L2-resident) column and compares
+//     (key, pixel) exactly — all queued slots at once, so their memory latencies overlap.  No separate key / index /
+//     rank arrays: 4 B of LDS per key.
 //   * the matched value is fetched where the RANK is known: neighbouring slots have neighbouring ranks, so
 //     sorted_source[q(rank)] is a coalesced read; values are scattered by pixel into the (dead) slot array and the
 //     column leaves with 16-byte stores.
+//   * 16-byte loads; the sample histogram size is known analytically (one block scan less).
+// A variant that ranked the slots of a run across lanes with DPP (v_mov_b32_dpp wave_shr:1 + lane masks in SGPRs)
+// instead of probing LDS was built and measured: correct, but every lane pays the whole window set-up and every
+// compare trip costs ~20 instructions for < 1 slot per lane — 3x the instructions per key of the LDS loop below
+// (DESIGN.md 4.2).
 // Columns this kernel cannot take (non-finite keys, many distinct massive ties) are flagged for the radix kernel of
 // sort.hip, which runs right behind it on the stream.
 #include "sort_common.h"
@@ -28,8 +29,6 @@ namespace optex {
 constexpr int R2_IDX_BITS = 14;  // pixel index inside a column, n <= 16384
 constexpr uint32_t R2_IDX_MASK = (1u << R2_IDX_BITS) - 1u;
 constexpr int R2_SUB_BITS = 18;
-constexpr int R2_STRIDE = 48;    // slots a window is responsible for
-constexpr int R2_FAST = 16;      // longest run ranked with DPP: 48 + 16 = one wave
 constexpr uint32_t R2_NONE = 0xffffffffu;
 constexpr int R2_QCAP = 256;     // slots per column that may need the exact path before the column goes to the radix kernel
 
@@ -41,28 +40,21 @@ struct R2 {
     static constexpr int NW2 = NBT / 2;                              // packed u16 counters
     static constexpr int PER = (NW2 + SORT_NT - 1) / SORT_NT;
     static constexpr int NWORDS = CAP / 32;
-    static constexpr int NWIN = (CAP + R2_STRIDE - 1) / R2_STRIDE;
-    static constexpr int TRIPS = (NWIN + SORT_NW - 1) / SORT_NW;
     static constexpr size_t LDS = (size_t)(CAP + NW2 + RK_COARSE + NWORDS + 4 + 32 + 32 + R2_QCAP) * 4;
     static_assert(NBT < (1 << (32 - R2_SUB_BITS - 1)), "bucket id and sub must fit 31 bits");
     static_assert(2 * NWORDS <= NW2, "big-bucket scratch aliases the counters");
 };
 
-__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {  // lane l receives lane l - 1 (lane 0: all ones)
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x138, 0xf, 0xf, false);
+// acc += (a < b): compare + add-with-carry, two instructions
+__device__ __forceinline__ void add_if_less(uint32_t& acc, uint32_t a, uint32_t b) {
+    asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
 }
-// acc += bit `lane` of a wave-uniform mask: one v_addc with the mask as carry-in
-__device__ __forceinline__ void add_lane_bit(uint32_t& acc, unsigned long long mask) {
-    unsigned long long carry_out;
-    asm volatile("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(acc), "=s"(carry_out) : "s"(mask));
-}
-__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 template <int ITEMS, bool VEC>
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match_kernel(SortArgs a) {
     using K = R2<ITEMS>;
-    constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, TRIPS = K::TRIPS;
+    constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* slot = reinterpret_cast<uint32_t*>(smem);  // [CAP] sub << 14 | pixel by bucket position; later the output
     uint32_t* cnt = slot + CAP;                          // [NW2] packed u16 bucket counts -> starts -> cursors
@@ -318,70 +310,72 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         __syncthreads();
     }
     SORT_PROBE(6);
-    // ---- 6c. ranks.  Window t = slots [48 t, 48 t + 64) of one wave; res[k] = pixel << 14 | rank of the slot this lane
-    //          is responsible for in its k-th window (or NONE).
-    const unsigned long long mle = (2ull << lane) - 1ull;  // lanes <= this one
-    const int nwin = (n + R2_STRIDE - 1) / R2_STRIDE;
-    uint32_t res[TRIPS];
+    // ---- 6c. ranks, slot side: slot p finds the bounds of its run in the start bitmap (one aligned 64-bit word per
+    //          wavefront trip) and counts the smaller words of the run; neighbouring lanes share runs, so the LDS
+    //          reads are broadcasts.  G slots per thread and trip keep G reads in flight.  res[r] = pixel << 14 | rank
+    //          of slot r * 1024 + tid.  A run in which two words share a sub goes to the exact path (6d).
+    constexpr int G = ITEMS < 4 ? ITEMS : 4;
+    const unsigned long long* bs64 = reinterpret_cast<const unsigned long long*>(bs);  // [NWORDS / 2 + 1]
+    uint32_t res[ITEMS];
 #pragma unroll
-    for (int k = 0; k < TRIPS; k++) {
-        res[k] = R2_NONE;
-        const int t = k * SORT_NW + w;  // wave-uniform
-        if (t < nwin) {
-            const int base = t * R2_STRIDE, p = base + lane;
-            const uint32_t my = p < n ? slot[p] : R2_NONE;
-            // bucket starts of [base, base + 64) as a 64-bit SGPR value, and of the 16 slots before the window
-            const int wi = base >> 5;
-            const uint32_t w0 = uniform(bs[wi]), w1 = uniform(bs[wi + 1]), w2 = uniform(bs[wi + 2]);
-            const uint32_t wp = wi > 0 ? uniform(bs[wi - 1]) : 0u;
-            const unsigned long long lo64 = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
-            const bool odd = (base & 31) != 0;  // base % 32 is 0 or 16
-            const unsigned long long B = odd ? ((lo64 >> 16) | ((unsigned long long)w2 << 48)) : lo64;
-            const uint32_t P16 = odd ? (w0 & 0xffffu) : (wp >> 16);
-            const unsigned long long le = B & mle, gt = B & ~mle;
-            const bool inwin = le != 0ull;                       // the run of this slot starts inside the window
-            const int s = inwin ? 63 - __clzll(le) : 0;
-            const int e = gt != 0ull ? __builtin_ctzll(gt) : 64;
-            const bool fast = p < n && inwin && s < R2_STRIDE && e - s <= R2_FAST;
-            // slots of the first 48 lanes that are NOT in a short run must be ranked the slow way by this window:
-            // a run that started before the window was ranked by the previous window iff it is short
-            bool slow = false;
-            if (p < n && lane < R2_STRIDE && !fast) {
-                if (inwin || P16 == 0u || gt == 0ull) slow = true;
-                else slow = e + 16 - (31 - __clz(P16)) > R2_FAST;
-            }
-            // lanes whose run has >= d members below them, d = 1, 2, ...: V_d = V_{d-1} & (N << (d - 1)) with N = the
-            // lanes that do not start a run — scalar work, independent of the vector compares
-            const unsigned long long N = ~B;
-            unsigned long long Vd = N & ballot64(fast);
-            uint32_t lt = 0u, tmp = my, nearest = 0xffffffffu;
-#pragma unroll 1
-            for (int d = 1; d < R2_FAST && Vd != 0ull; d++) {
-                tmp = dpp_wave_shr1(tmp);  // the slot d lanes below
-                const unsigned long long less = ballot64(tmp < my);
-                const uint32_t x = tmp ^ my;
-                nearest = x < nearest ? x : nearest;       // equal subs show up as a difference below 2^14
-                add_lane_bit(lt, less & Vd);               // the slot d below is smaller
-                add_lane_bit(lt, (Vd & ~less) >> d);       // ... or larger: then its lane counts this one
-                Vd &= N << d;
-            }
-            // a pair with equal subs sends its whole run to the exact path (the rare neighbour of another run that
-            // happens to share a sub only costs time)
-            const unsigned long long cm = ballot64(fast && (nearest >> R2_IDX_BITS) == 0u);
-            const bool collided = cm != 0ull && ((cm >> s) & ((1ull << (fast ? e - s : 1)) - 1ull)) != 0ull;
-            if (fast && !collided) {
-                res[k] = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(base + s + (int)lt);
-            } else if (fast || slow) {
-                bool in_big = false;  // the all-equal pass left pixel << 14 | rank in the slots of oversized buckets
-                for (unsigned bi = 0; bi < nbig; bi++) in_big = in_big || ((uint32_t)p - misc[2 + 2 * bi] < misc[3 + 2 * bi]);
-                if (in_big) {
-                    res[k] = my;
+    for (int r0 = 0; r0 < ITEMS; r0 += G) {
+        uint32_t ps[G], pc[G], pk[G], lt[G], eq[G];
+        uint32_t trips = 0;
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            const int p = (r0 + q) * SORT_NT + tid;
+            ps[q] = 0u; pc[q] = 0u; pk[q] = 0u; lt[q] = 0u; eq[q] = 0u;
+            res[r0 + q] = R2_NONE;
+            if (p < n) {
+                // the 64 slots of this wave trip are one aligned 64-bit word of the bitmap (wave-uniform); a run of
+                // <= RK_BIG < 64 slots starts in it or in the word before and ends in it or the next
+                const int wq = p >> 6, lb = p & 63;
+                const unsigned long long B = bs64[wq];
+                const unsigned long long A = wq > 0 ? bs64[wq - 1] : 0ull;
+                const unsigned long long Cw = bs64[wq + 1];
+                const unsigned long long le = B & (~0ull >> (63 - lb));
+                const unsigned long long gt = lb == 63 ? 0ull : (B & (~0ull << (lb + 1)));
+                bool in_big = false;
+                uint32_t s = 0u, e2 = 0u;
+                if (le != 0ull) s = (uint32_t)(wq * 64 + 63 - __clzll(le));
+                else if (A != 0ull) s = (uint32_t)((wq - 1) * 64 + 63 - __clzll(A));
+                else in_big = true;  // no start within 64 slots below: part of an oversized run
+                if (gt != 0ull) e2 = (uint32_t)(wq * 64 + __builtin_ctzll(gt));
+                else if (Cw != 0ull) e2 = (uint32_t)((wq + 1) * 64 + __builtin_ctzll(Cw));
+                else in_big = true;
+                pk[q] = slot[p];
+                if (in_big || e2 - s > (uint32_t)RK_BIG) {
+                    res[r0 + q] = pk[q];  // the all-equal pass left pixel << 14 | rank in the slots of oversized buckets
                 } else {
-                    const uint32_t qi = atomicAdd(&misc[20], 1u);
-                    if (qi < (uint32_t)R2_QCAP) queue[qi] = (uint32_t)p;
+                    ps[q] = s;
+                    pc[q] = e2 - s;
+                    trips = pc[q] > trips ? pc[q] : trips;
                 }
             }
         }
+        // trip j looks at member j of the run; a lane whose run is shorter re-reads its own slot, which adds nothing
+        // to lt and one to eq — no per-lane masking of the two counters
+#pragma unroll 1
+        for (uint32_t j = 0; j < trips; j++) {
+#pragma unroll
+            for (int q = 0; q < G; q++) {
+                const uint32_t kj = slot[j < pc[q] ? ps[q] + j : (uint32_t)((r0 + q) * SORT_NT + tid)];
+                add_if_less(lt[q], kj, pk[q]);
+                add_if_less(eq[q], kj ^ pk[q], 1u << R2_IDX_BITS);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            if (pc[q]) {
+                if (eq[q] == trips - pc[q] + 1u) {  // only itself shares its sub
+                    res[r0 + q] = ((pk[q] & R2_IDX_MASK) << R2_IDX_BITS) | (ps[q] + lt[q]);
+                } else {
+                    const uint32_t qi = atomicAdd(&misc[20], 1u);
+                    if (qi < (uint32_t)R2_QCAP) queue[qi] = (uint32_t)((r0 + q) * SORT_NT + tid);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");  // keep the next trip's bitmap reads below this trip's loop (64-VGPR budget)
     }
     // ---- 6d. the exact path, one queued slot per thread (all at once: their memory latencies overlap): long runs and
     //          runs in which two slots share a sub (ties, or distinct keys closer than the refinement resolves)
@@ -422,7 +416,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #ifdef R2_DEBUG
     if (blockIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < TRIPS; k++) a.dbg[2 * CAP + (k * SORT_NW + w) * 64 + lane] = res[k];
+        for (int k = 0; k < ITEMS; k++) a.dbg[2 * CAP + k * SORT_NT + tid] = res[k];
     }
 #endif
     SORT_PROBE(7);
@@ -433,15 +427,15 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const float qv = ssrt[quantile_index(qres != R2_NONE ? (qres & R2_IDX_MASK) : 0u, ns, (unsigned)n, a.inv_2nt)];
     constexpr int FCH = 8;  // loads of a chunk are all in flight before the first LDS write waits for one
 #pragma unroll
-    for (int k0 = 0; k0 < TRIPS; k0 += FCH) {
+    for (int k0 = 0; k0 < ITEMS; k0 += FCH) {
         float v[FCH];
 #pragma unroll
-        for (int k = k0; k < k0 + FCH && k < TRIPS; k++) {
+        for (int k = k0; k < k0 + FCH && k < ITEMS; k++) {
             const uint32_t rank = res[k] != R2_NONE ? (res[k] & R2_IDX_MASK) : 0u;
             v[k - k0] = ssrt[quantile_index(rank, ns, (unsigned)n, a.inv_2nt)];
         }
 #pragma unroll
-        for (int k = k0; k < k0 + FCH && k < TRIPS; k++)
+        for (int k = k0; k < k0 + FCH && k < ITEMS; k++)
             if (res[k] != R2_NONE) val[res[k] >> R2_IDX_BITS] = v[k - k0];
     }
     if (qres != R2_NONE) val[qres >> R2_IDX_BITS] = qv;

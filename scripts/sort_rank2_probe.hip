@@ -27,7 +27,7 @@ int main() {
     int occ = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 1024, lds);
     printf("LDS %zu B per workgroup, occupancy %d workgroups per CU\n", lds, occ);
-    const char* names[] = {"load+minmax", "coarse hist", "equalise", "bucket+count", "scan+bitmap", "place(+big)", "rank windows",
+    const char* names[] = {"load+minmax", "coarse hist", "equalise", "bucket+count", "scan+bitmap", "place(+big)", "rank slots+exact",
                            "fetch+scatter", "store issue"};
     for (int ncols : {256, 512, maxcols}) {
         optex::SortArgs a{};
