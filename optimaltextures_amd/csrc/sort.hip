@@ -582,6 +582,7 @@ static int launch_sort(const SortArgs& a, int ncols, int* flags, void* large_ws,
     if (a.n <= 2 * SORT_NT) return launch_sort_items<2, MODE>(a, ncols, flags, st);
     if (a.n <= 4 * SORT_NT) return launch_sort_items<4, MODE>(a, ncols, flags, st);
     if (a.n <= 8 * SORT_NT) return launch_sort_items<8, MODE>(a, ncols, flags, st);
+    if (a.n <= 12 * SORT_NT) return launch_sort_items<12, MODE>(a, ncols, flags, st);
     if (a.n <= 16 * SORT_NT) return launch_sort_items<16, MODE>(a, ncols, flags, st);
     // longer than one LDS: global multi-pass radix (sort_large.hip)
     return sort_large(MODE, a, ncols, large_ws, st);

@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d) {
 size_t sort_large_ws_bytes(long n, int ncols);
 int sort_large(int mode, const SortArgs& a, int ncols, void* ws, hipStream_t st);
 
-// two-columns-per-CU match kernel (sort_rank2.hip); items = 2 / 4 / 8 / 16 keys per thread
+// two-columns-per-CU match kernel (sort_rank2.hip); items = 2 / 4 / 8 / 12 / 16 keys per thread
 int launch_rank_match(int items, const SortArgs& a, int ncols, hipStream_t st);
 
 }  // namespace optex

@@ -30,17 +30,18 @@ constexpr int R2_IDX_BITS = 14;  // pixel index inside a column, n <= 16384
 constexpr uint32_t R2_IDX_MASK = (1u << R2_IDX_BITS) - 1u;
 constexpr int R2_SUB_BITS = 18;
 constexpr uint32_t R2_NONE = 0xffffffffu;
-constexpr int R2_QCAP = 256;     // slots per column that may need the exact path before the column goes to the radix kernel
+constexpr int R2_TMAX = 6;       // runs longer than this are ranked one slot per thread (6d), not in the G-wide loop
 
 template <int ITEMS>
 struct R2 {
     static constexpr int CAP = ITEMS * SORT_NT;
-    static constexpr int NB = ITEMS == 16 ? CAP * 5 / 16 : CAP / 2;  // fine buckets handed out by the equalisation
+    static constexpr int NB = ITEMS == 16 ? CAP * 3 / 8 : CAP / 2;   // fine buckets handed out by the equalisation (16: what 80 KiB allow)
     static constexpr int NBT = NB + RK_COARSE;                       // + 1 per coarse bin; even; < 2^13
     static constexpr int NW2 = NBT / 2;                              // packed u16 counters
     static constexpr int PER = (NW2 + SORT_NT - 1) / SORT_NT;
     static constexpr int NWORDS = CAP / 32;
-    static constexpr size_t LDS = (size_t)(CAP + NW2 + RK_COARSE + NWORDS + 4 + 32 + 32 + R2_QCAP) * 4;
+    static constexpr int QCAP = NW2;  // queued slots per column (the queue aliases the dead counters)
+    static constexpr size_t LDS = (size_t)(CAP + NW2 + RK_COARSE + NWORDS + 4 + 32 + 32) * 4;
     static_assert(NBT < (1 << (32 - R2_SUB_BITS - 1)), "bucket id and sub must fit 31 bits");
     static_assert(2 * NWORDS <= NW2, "big-bucket scratch aliases the counters");
 };
@@ -54,7 +55,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__bui
 template <int ITEMS, bool VEC>
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match_kernel(SortArgs a) {
     using K = R2<ITEMS>;
-    constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS;
+    constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, QCAP = K::QCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* slot = reinterpret_cast<uint32_t*>(smem);  // [CAP] sub << 14 | pixel by bucket position; later the output
     uint32_t* cnt = slot + CAP;                          // [NW2] packed u16 bucket counts -> starts -> cursors
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     uint32_t* bs = c1 + RK_COARSE;                       // [NWORDS + 4] bit p = slot p starts a bucket
     uint32_t* red = bs + NWORDS + 4;                     // [32]
     uint32_t* misc = red + 32;                           // [32] nbig, noteq, (start, count) x RK_MAXBIG, [20] queue length
-    uint32_t* queue = misc + 32;                         // [R2_QCAP] slots that need the exact path
+    uint32_t* queue = cnt;                               // [QCAP] slots for the one-per-thread pass (6c/6d), then their results
     uint32_t* bitmap = cnt;                              // [NWORDS] big-bucket pass (counters are dead by then)
     uint32_t* bpre = cnt + NWORDS;                       // [NWORDS]
 
@@ -346,6 +347,9 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 pk[q] = slot[p];
                 if (in_big || e2 - s > (uint32_t)RK_BIG) {
                     res[r0 + q] = pk[q];  // the all-equal pass left pixel << 14 | rank in the slots of oversized buckets
+                } else if (e2 - s > (uint32_t)R2_TMAX) {
+                    const uint32_t qi = atomicAdd(&misc[20], 1u);  // long run: one-per-thread pass
+                    if (qi < (uint32_t)QCAP) queue[qi] = (uint32_t)p;
                 } else {
                     ps[q] = s;
                     pc[q] = e2 - s;
@@ -371,23 +375,24 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
                     res[r0 + q] = ((pk[q] & R2_IDX_MASK) << R2_IDX_BITS) | (ps[q] + lt[q]);
                 } else {
                     const uint32_t qi = atomicAdd(&misc[20], 1u);
-                    if (qi < (uint32_t)R2_QCAP) queue[qi] = (uint32_t)((r0 + q) * SORT_NT + tid);
+                    if (qi < (uint32_t)QCAP) queue[qi] = (uint32_t)((r0 + q) * SORT_NT + tid);
                 }
             }
         }
         asm volatile("" ::: "memory");  // keep the next trip's bitmap reads below this trip's loop (64-VGPR budget)
     }
-    // ---- 6d. the exact path, one queued slot per thread (all at once: their memory latencies overlap): long runs and
-    //          runs in which two slots share a sub (ties, or distinct keys closer than the refinement resolves)
+    SORT_PROBE(7);
+    // ---- 6d. queued slots, one per thread: runs longer than R2_TMAX (the G-wide loop above would make every lane wait
+    //          for the longest run of its wave) and runs in which two words share a sub — there the real keys decide
+    //          (re-read from the L2-resident column), then the pixels.  The queue entry becomes pixel << 14 | rank.
     __syncthreads();
     const uint32_t qn = misc[20];
-    if (qn > (uint32_t)R2_QCAP) {  // tie-heavy column: radix kernel
+    if (qn > (uint32_t)QCAP) {  // tie-heavy column: radix kernel
         if (tid == 0) a.flags[col] = 1;
         return;
     }
-    uint32_t qres = R2_NONE;
-    if ((uint32_t)tid < qn) {
-        const int p = (int)queue[tid];
+    for (uint32_t i = tid; i < qn; i += SORT_NT) {
+        const int p = (int)queue[i];
         const uint32_t my = slot[p];
         int wa = p >> 5;
         uint32_t m = bs[wa] & (0xffffffffu >> (31 - (p & 31)));
@@ -398,20 +403,27 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         m = bs[wb] & (0xffffffffu << (q1 & 31));
         while (m == 0u) m = bs[++wb];  // the sentinel at n ends the search
         const int E = wb * 32 + __builtin_ctz(m);
-        // count the smaller members of the run; equal subs are decided by the real keys (then pixels)
-        const uint32_t myk = f2key(src[my & R2_IDX_MASK]);
-        uint32_t lt = 0u;
+        uint32_t lt = 0u, ties = 0u;
         for (int j = S; j < E; j++) {
             const uint32_t oj = slot[j];
-            if (j == p) continue;
-            if (((oj ^ my) >> R2_IDX_BITS) == 0u) {
-                const uint32_t ok = f2key(src[oj & R2_IDX_MASK]);
-                lt += (ok < myk || (ok == myk && (oj & R2_IDX_MASK) < (my & R2_IDX_MASK))) ? 1u : 0u;
-            } else {
-                lt += oj < my ? 1u : 0u;
+            add_if_less(lt, oj, my);
+            add_if_less(ties, oj ^ my, 1u << R2_IDX_BITS);
+        }
+        if (ties > 1u) {  // some other word shares the sub: decide those pairs by the keys
+            const uint32_t myk = f2key(src[my & R2_IDX_MASK]);
+            lt = 0u;
+            for (int j = S; j < E; j++) {
+                const uint32_t oj = slot[j];
+                if (j == p) continue;
+                if (((oj ^ my) >> R2_IDX_BITS) == 0u) {
+                    const uint32_t ok = f2key(src[oj & R2_IDX_MASK]);
+                    lt += (ok < myk || (ok == myk && (oj & R2_IDX_MASK) < (my & R2_IDX_MASK))) ? 1u : 0u;
+                } else {
+                    lt += oj < my ? 1u : 0u;
+                }
             }
         }
-        qres = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(S + (int)lt);
+        queue[i] = ((my & R2_IDX_MASK) << R2_IDX_BITS) | (uint32_t)(S + (int)lt);
     }
 #ifdef R2_DEBUG
     if (blockIdx.x == 0) {
@@ -419,12 +431,11 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (int k = 0; k < ITEMS; k++) a.dbg[2 * CAP + k * SORT_NT + tid] = res[k];
     }
 #endif
-    SORT_PROBE(7);
+    SORT_PROBE(8);
     // ---- 7. out[pixel] = sorted_source[q(rank)]: read where the ranks are neighbours (coalesced), scatter by pixel
     //         into the slot array (every slot has been read: barrier), leave with 16-byte stores
     __syncthreads();
     float* val = reinterpret_cast<float*>(slot);
-    const float qv = ssrt[quantile_index(qres != R2_NONE ? (qres & R2_IDX_MASK) : 0u, ns, (unsigned)n, a.inv_2nt)];
     constexpr int FCH = 8;  // loads of a chunk are all in flight before the first LDS write waits for one
 #pragma unroll
     for (int k0 = 0; k0 < ITEMS; k0 += FCH) {
@@ -438,9 +449,12 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (int k = k0; k < k0 + FCH && k < ITEMS; k++)
             if (res[k] != R2_NONE) val[res[k] >> R2_IDX_BITS] = v[k - k0];
     }
-    if (qres != R2_NONE) val[qres >> R2_IDX_BITS] = qv;
+    for (uint32_t i = tid; i < qn; i += SORT_NT) {  // each thread reads back the entries it wrote
+        const uint32_t r = queue[i];
+        val[r >> R2_IDX_BITS] = ssrt[quantile_index(r & R2_IDX_MASK, ns, (unsigned)n, a.inv_2nt)];
+    }
     __syncthreads();
-    SORT_PROBE(8);
+    SORT_PROBE(9);
     if (VEC && a.out_vec) {
 #pragma unroll
         for (int q = 0; q < ITEMS / 4; q++) {
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     } else {
         for (int e = tid; e < n; e += SORT_NT) o[e] = val[e];
     }
-    SORT_PROBE(9);
+    SORT_PROBE(10);
 }
 
 template <int ITEMS>
@@ -488,6 +502,7 @@ int launch_rank_match(int items, const SortArgs& a, int ncols, hipStream_t st) {
         case 2: return launch_rank_match_items<2>(a, ncols, st);
         case 4: return launch_rank_match_items<4>(a, ncols, st);
         case 8: return launch_rank_match_items<8>(a, ncols, st);
+        case 12: return launch_rank_match_items<12>(a, ncols, st);
         default: return launch_rank_match_items<16>(a, ncols, st);
     }
 }

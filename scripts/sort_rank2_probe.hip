@@ -27,7 +27,7 @@ int main() {
     int occ = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 1024, lds);
     printf("LDS %zu B per workgroup, occupancy %d workgroups per CU\n", lds, occ);
-    const char* names[] = {"load+minmax", "coarse hist", "equalise", "bucket+count", "scan+bitmap", "place(+big)", "rank slots+exact",
+    const char* names[] = {"load+minmax", "coarse hist", "equalise", "bucket+count", "scan+bitmap", "place(+big)", "rank slots", "queued slots",
                            "fetch+scatter", "store issue"};
     for (int ncols : {256, 512, maxcols}) {
         optex::SortArgs a{};
@@ -46,13 +46,13 @@ int main() {
         }
         std::vector<long long> p((size_t)ncols * 16);
         hipMemcpy(p.data(), probe, p.size() * 8, hipMemcpyDeviceToHost);
-        double tot[9] = {0}, all = 0;
+        double tot[10] = {0}, all = 0;
         for (int c = 0; c < ncols; c++)
-            for (int i = 0; i < 9; i++) tot[i] += (double)(p[(size_t)c * 16 + i + 1] - p[(size_t)c * 16 + i]);
-        for (int i = 0; i < 9; i++) all += tot[i];
+            for (int i = 0; i < 10; i++) tot[i] += (double)(p[(size_t)c * 16 + i + 1] - p[(size_t)c * 16 + i]);
+        for (int i = 0; i < 10; i++) all += tot[i];
         printf("%d columns: kernel %.1f us = %.2f TB/s algorithmic; per column %.2f us in-kernel (100 MHz ticks)\n", ncols,
                ms * 1e3, 12.0 * n * ncols / (ms * 1e-3) / 1e12, all / ncols / 100.0);
-        for (int i = 0; i < 9; i++) printf("  %-16s %8.1f ticks  %5.1f %%\n", names[i], tot[i] / ncols, 100.0 * tot[i] / all);
+        for (int i = 0; i < 10; i++) printf("  %-16s %8.1f ticks  %5.1f %%\n", names[i], tot[i] / ncols, 100.0 * tot[i] / all);
     }
     return 0;
 }
