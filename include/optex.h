@@ -153,6 +153,11 @@ int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, lon
  * ------------------------------------------------------------------------------------------------- */
 int optex_vgg_glue(const float* x, const float* bias, float* out, int N, int C, int H, int W, int relu, int pool, int up,
                    int pad, void* stream);
+/* The same pass with the memory layout of each side chosen independently: 0 = NCHW (planar), 1 = NHWC (channels-last,
+ * what MIOpen's fp32 implicit-GEMM convolutions prefer).  A layout change costs nothing extra: the glue reads one and
+ * writes the other.  NHWC on both sides needs C % 4 == 0. */
+int optex_vgg_glue_layout(const float* x, const float* bias, float* out, int N, int C, int H, int W, int relu, int pool,
+                          int up, int pad, int in_nhwc, int out_nhwc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Measurement (no reference counterpart; the reference only wall-clocks forward(), optex.py:285-289).

@@ -36,6 +36,7 @@ SIGNATURES = {
     "optex_ot_loop_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I]),
     "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _I, _P, _F, _I, _P, _P]),
     "optex_vgg_glue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "optex_vgg_glue_layout": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "optex_prof_enable": (_I, [_I]),
     "optex_prof_num_classes": (_I, []),
     "optex_prof_class_name": (_c.c_char_p, [_I]),

@@ -182,18 +182,34 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
     return x
 
 
-def vgg_glue(x, bias=None, relu=False, pool=False, up=False, pad=0):
-    """pad(up(pool(relu(x + bias)))) in one pass over an NCHW fp32 tensor (vgg.py's module glue, see include/optex.h)"""
-    x = _f32c(x).contiguous()
+def vgg_glue(x, bias=None, relu=False, pool=False, up=False, pad=0, out_nhwc=False):
+    """pad(up(pool(relu(x + bias)))) in one pass over a fp32 tensor of logical shape [N, C, H, W] (vgg.py's module glue,
+    see include/optex.h).  x is either NCHW-contiguous or channels-last (a permuted view of [N, H, W, C] memory, what
+    MIOpen's convolutions return for channels-last inputs); out_nhwc picks the layout of the result, again returned
+    with the logical shape [N, C, Ho, Wo].  A layout change rides along for free."""
+    x = _f32c(x)
     n, c, h, w = x.shape
+    if x.is_contiguous():
+        in_nhwc = False
+    elif x.permute(0, 2, 3, 1).is_contiguous():
+        in_nhwc = True
+    else:
+        x, in_nhwc = x.contiguous(), False
     hm = (h + 1) // 2 if pool else (2 * h if up else h)
     wm = (w + 1) // 2 if pool else (2 * w if up else w)
-    out = torch.empty((n, c, hm + 2 * pad, wm + 2 * pad), dtype=torch.float32, device=x.device)
+    ho, wo = hm + 2 * pad, wm + 2 * pad
+    if in_nhwc and out_nhwc and c % 4:
+        raise ValueError("channels-last on both sides needs C % 4 == 0")
+    if out_nhwc:
+        buf = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        out = buf.permute(0, 3, 1, 2)
+    else:
+        buf = out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
     if bias is not None:
         bias = _f32c(bias).contiguous()
         assert bias.numel() == c
-    check(_lib.lib().optex_vgg_glue(ptr(x), ptr(bias), ptr(out), n, c, h, w, int(relu), int(pool), int(up), int(pad),
-                                    stream_ptr()))
+    check(_lib.lib().optex_vgg_glue_layout(ptr(x), ptr(bias), ptr(buf), n, c, h, w, int(relu), int(pool), int(up),
+                                           int(pad), int(in_nhwc), int(out_nhwc), stream_ptr()))
     return out
 
 

@@ -53,25 +53,51 @@ def _synthetic_init(model: nn.Sequential, seed: int):
                 m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.05)
 
 
+# Layout policy of the fused codec path: "mixed" runs every 3x3 convolution with >= 64 output channels
+# channels-last (MIOpen's MFMA implicit-GEMM kernels: 8-20 % faster than the planar Winograd assembly at these shapes,
+# scripts/conv_layout_probe.py) and keeps the 3-channel ends and the feature hand-off to the OT kernels planar; the
+# glue pass between two convolutions changes the layout for free.  "nchw" keeps everything planar.
+CODEC_LAYOUT = os.environ.get("OPTEX_CODEC_LAYOUT", "mixed")
+
+
+def _conv_channels_last(m: nn.Conv2d) -> bool:
+    # 64 -> 3 (the last decoder convolution) is the one wide 3x3 shape MIOpen runs faster planar (2.5 vs 3.0 ms)
+    return CODEC_LAYOUT == "mixed" and m.kernel_size == (3, 3) and m.out_channels >= 64
+
+
+def _weight(m: nn.Conv2d, channels_last: bool):
+    if not channels_last:
+        return m.weight
+    w = getattr(m, "_optex_w_cl", None)
+    if w is None or w.device != m.weight.device or m.weight._version != getattr(m, "_optex_w_cl_src", -1):
+        w = m.weight.detach().contiguous(memory_format=torch.channels_last)
+        m._optex_w_cl, m._optex_w_cl_src = w, m.weight._version
+    return w
+
+
 def run_fused(model: nn.Sequential, x):
     """Run one of the Sequentials above with every convolution on MIOpen (bias-free) and everything BETWEEN two
-    convolutions — bias, ReLU, max-pool / upsample, reflection pad — in one pass of optex_vgg_glue (csrc/glue.hip).
-    Bit-identical to model(x): only the kernel boundaries move."""
+    convolutions — bias, ReLU, max-pool / upsample, reflection pad, and the change of memory layout the next
+    convolution wants — in one pass of optex_vgg_glue_layout (csrc/glue.hip).  With CODEC_LAYOUT = "nchw" the result is
+    bit-identical to model(x) (only the kernel boundaries move); with "mixed" the convolutions run through other MIOpen
+    kernels, i.e. a different fp32 summation order inside the convolution."""
     from . import ops
     cur, bias = x, None
     relu = pool = up = False
     pad = 0
 
-    def flush():
+    def flush(next_nhwc):
         nonlocal cur, bias, relu, pool, up, pad
-        if bias is not None or relu or pool or up or pad:
-            cur = ops.vgg_glue(cur, bias, relu=relu, pool=pool, up=up, pad=pad)
+        cur_nhwc = (not cur.is_contiguous()) and cur.permute(0, 2, 3, 1).is_contiguous()
+        if bias is not None or relu or pool or up or pad or cur_nhwc != next_nhwc or not (cur_nhwc or cur.is_contiguous()):
+            cur = ops.vgg_glue(cur, bias, relu=relu, pool=pool, up=up, pad=pad, out_nhwc=next_nhwc)
         bias, relu, pool, up, pad = None, False, False, False, 0
 
     for m in model:
         if isinstance(m, nn.Conv2d):
-            flush()
-            cur = torch.nn.functional.conv2d(cur, m.weight, None)
+            cl = _conv_channels_last(m)
+            flush(cl)
+            cur = torch.nn.functional.conv2d(cur, _weight(m, cl), None)
             bias = m.bias
         elif isinstance(m, nn.ReLU):
             assert not (pool or up or pad), "glue order is bias, relu, pool / upsample, pad"
@@ -86,7 +112,7 @@ def run_fused(model: nn.Sequential, x):
             pad = 1
         else:
             raise TypeError(f"unexpected module {type(m).__name__} in the VGG codec")
-    flush()
+    flush(False)
     return cur
 
 

@@ -638,21 +638,40 @@ def test_vgg_glue_matches_torch_modules_bit_exact(dev, N, C, H, W, relu, pool, u
     if not (relu or pool or up):  # bias-free pad-only form (decoder input)
         assert torch.equal(ops.vgg_glue(x.to(dev), None, pad=pad).cpu(),
                            torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect") if pad else x)
+    # the same pass with either side channels-last (what MIOpen's implicit-GEMM convolutions take and return)
+    x_cl = x.to(dev).contiguous(memory_format=torch.channels_last)
+    for in_cl, out_cl in ((False, True), (True, False), (True, True)):
+        if in_cl and out_cl and C % 4:
+            continue
+        got = ops.vgg_glue(x_cl if in_cl else x.to(dev), b.to(dev), relu=relu, pool=pool, up=up, pad=pad, out_nhwc=out_cl)
+        assert got.shape == want.shape
+        assert got.permute(0, 2, 3, 1).is_contiguous() if out_cl else got.is_contiguous()
+        assert torch.equal(got.cpu(), want), f"in_nhwc={in_cl} out_nhwc={out_cl}"
 
 
 @pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_vgg_codec_fused_path_equals_module_path(dev, depth):
-    """Encoder.features / Decoder.decode through the fused glue == the plain nn.Sequential on the same device"""
+    """Encoder.features / Decoder.decode through the fused glue == the plain nn.Sequential on the same device, in both
+    layout policies ("mixed": the wide convolutions run channels-last through other MIOpen kernels)"""
+    from optimaltextures_amd import vgg
     from optimaltextures_amd.vgg import Decoder, Encoder
     enc, dec = Encoder(depth).to(dev).eval(), Decoder(depth).to(dev).eval()
     x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(depth)).to(dev)
-    with torch.inference_mode():
-        f_fused, f_plain = enc.features(x), enc.model(x)
-        # the conv runs bias-free + our add vs MIOpen's own bias handling: same fp32 add, allow 1 ulp-level noise only
-        assert torch.allclose(f_fused, f_plain, rtol=0, atol=1e-5 * float(f_plain.abs().max()))
-        d_fused, d_plain = dec.decode(f_plain), dec.model(f_plain)
-        assert d_fused.shape == d_plain.shape == x.shape
-        assert torch.allclose(d_fused, d_plain, rtol=0, atol=1e-5 * float(d_plain.abs().max()))
+    saved = vgg.CODEC_LAYOUT
+    try:
+        for layout, tol in (("nchw", 1e-5), ("mixed", 5e-5)):
+            vgg.CODEC_LAYOUT = layout
+            with torch.inference_mode():
+                f_fused, f_plain = enc.features(x), enc.model(x)
+                # bias-free conv + our add vs MIOpen's own bias handling (and, for "mixed", another convolution kernel):
+                # fp32 summation-order noise only
+                assert f_fused.is_contiguous() and f_fused.shape == f_plain.shape
+                assert torch.allclose(f_fused, f_plain, rtol=0, atol=tol * float(f_plain.abs().max())), layout
+                d_fused, d_plain = dec.decode(f_plain), dec.model(f_plain)
+                assert d_fused.shape == d_plain.shape == x.shape and d_fused.is_contiguous()
+                assert torch.allclose(d_fused, d_plain, rtol=0, atol=tol * float(d_plain.abs().max())), layout
+    finally:
+        vgg.CODEC_LAYOUT = saved
 
 
 # ================================================================================================ N1 / N2 "next" rows
