@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="independent textures per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="independent textures per GPU per step (16 / 32 / 64 measured: 176 / 183 / 198 textures/s)")
     ap.add_argument("--hist_mode", type=str, default="cdf", choices=["cdf", "sort", "chol", "pca", "sym"])
     ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused", help="one extra step each (N = 1 only); 'fused' = the re-associated rotation fast path")
     ap.add_argument("--no_cpu_baseline", action="store_true")
