@@ -66,13 +66,19 @@ def _conv_channels_last(m: nn.Conv2d) -> bool:
 
 
 def _weight(m: nn.Conv2d, channels_last: bool):
+    """the convolution's weight in the layout of its input; the channels-last copy is cached per module and refreshed
+    when the parameter is replaced, moved or (for tensors that track it) modified in place"""
     if not channels_last:
         return m.weight
-    w = getattr(m, "_optex_w_cl", None)
-    if w is None or w.device != m.weight.device or m.weight._version != getattr(m, "_optex_w_cl_src", -1):
-        w = m.weight.detach().contiguous(memory_format=torch.channels_last)
-        m._optex_w_cl, m._optex_w_cl_src = w, m.weight._version
-    return w
+    try:
+        version = m.weight._version
+    except RuntimeError:  # inference tensors do not track a version counter
+        version = -1
+    key = (m.weight.data_ptr(), str(m.weight.device), version)
+    if getattr(m, "_optex_w_cl_key", None) != key:
+        m._optex_w_cl = m.weight.detach().contiguous(memory_format=torch.channels_last)
+        m._optex_w_cl_key = key
+    return m._optex_w_cl
 
 
 def run_fused(model: nn.Sequential, x):
