@@ -16,9 +16,10 @@ import csv
 import json
 import re
 
-CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"), ("col_hist_kernel", "col_hist"),
-            ("col_minmax_kernel", "col_minmax"), ("cdf_lut_kernel", "cdf_lut"), ("glue_kernel", "vgg_glue"),
-            ("rank_columns_kernel", "sort_rank"), ("sort_columns_kernel", "sort_radix"), ("gram_kernel", "gram"),
+CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"),
+            ("col_hist_kernel", "col_hist"), ("col_minmax_kernel", "col_minmax"), ("cdf_lut_kernel", "cdf_lut"),
+            ("glue_kernel", "vgg_glue"), ("glue_nhwc_kernel", "vgg_glue"), ("glue_transpose", "vgg_glue"),
+            ("rank_match_kernel", "sort_match"), ("rank_columns_kernel", "sort_rank"), ("sort_columns_kernel", "sort_radix"), ("gram_kernel", "gram"),
             ("col_mean_kernel", "col_mean"), ("householder_apply", "householder")]
 
 
