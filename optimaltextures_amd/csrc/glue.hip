@@ -197,10 +197,22 @@ __global__ __launch_bounds__(256) void glue_transpose_wide_kernel(GlueLArgs a) {
             }
         }
         __syncthreads();
+        if (a.Wo % 2 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0) {
+            // even rows: 8-byte stores (the planar side is store-issue-bound), 32 lanes x 2 pixels, 8 channel rows a pass
+            const int p2 = (tid & 31) * 2, cr = tid >> 5;
 #pragma unroll
-        for (int k = 0; k < TC / 4; k++) {
-            const int ch = cq + 4 * k, ox = ox0 + px, c = c0 + ch;
-            if (ox < a.Wo && c < a.C) a.out[(((size_t)n * a.C + c) * a.Ho + oy) * a.Wo + ox] = tile[ch][px];
+            for (int k = 0; k < TC / 8; k++) {
+                const int ch = cr + 8 * k, ox = ox0 + p2, c = c0 + ch;
+                if (ox < a.Wo && c < a.C)   // Wo and ox even: ox + 1 < Wo as well
+                    *reinterpret_cast<float2*>(a.out + (((size_t)n * a.C + c) * a.Ho + oy) * a.Wo + ox) =
+                        make_float2(tile[ch][p2], tile[ch][p2 + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TC / 4; k++) {
+                const int ch = cq + 4 * k, ox = ox0 + px, c = c0 + ch;
+                if (ox < a.Wo && c < a.C) a.out[(((size_t)n * a.C + c) * a.Ho + oy) * a.Wo + ox] = tile[ch][px];
+            }
         }
     } else {
 #pragma unroll

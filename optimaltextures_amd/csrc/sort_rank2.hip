@@ -311,12 +311,11 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         __syncthreads();
     }
     SORT_PROBE(6);
-    // ---- 6c. ranks, slot side: slot p finds the bounds of its run in the start bitmap (one aligned 64-bit word per
-    //          wavefront trip) and counts the smaller words of the run; neighbouring lanes share runs, so the LDS
+    // ---- 6c. ranks, slot side: slot p finds the bounds of its run in a 14-bit window of the start bitmap and counts
+    //          the smaller words of the run; neighbouring lanes share runs, so the LDS
     //          reads are broadcasts.  G slots per thread and trip keep G reads in flight.  res[r] = pixel << 14 | rank
     //          of slot r * 1024 + tid.  A run in which two words share a sub goes to the exact path (6d).
     constexpr int G = ITEMS < 4 ? ITEMS : 4;
-    const unsigned long long* bs64 = reinterpret_cast<const unsigned long long*>(bs);  // [NWORDS / 2 + 1]
     uint32_t res[ITEMS];
 #pragma unroll
     for (int r0 = 0; r0 < ITEMS; r0 += G) {
@@ -328,26 +327,21 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             ps[q] = 0u; pc[q] = 0u; pk[q] = 0u; lt[q] = 0u; eq[q] = 0u;
             res[r0 + q] = R2_NONE;
             if (p < n) {
-                // the 64 slots of this wave trip are one aligned 64-bit word of the bitmap (wave-uniform); a run of
-                // <= RK_BIG < 64 slots starts in it or in the word before and ends in it or the next
-                const int wq = p >> 6, lb = p & 63;
-                const unsigned long long B = bs64[wq];
-                const unsigned long long A = wq > 0 ? bs64[wq - 1] : 0ull;
-                const unsigned long long Cw = bs64[wq + 1];
-                const unsigned long long le = B & (~0ull >> (63 - lb));
-                const unsigned long long gt = lb == 63 ? 0ull : (B & (~0ull << (lb + 1)));
-                bool in_big = false;
-                uint32_t s = 0u, e2 = 0u;
-                if (le != 0ull) s = (uint32_t)(wq * 64 + 63 - __clzll(le));
-                else if (A != 0ull) s = (uint32_t)((wq - 1) * 64 + 63 - __clzll(A));
-                else in_big = true;  // no start within 64 slots below: part of an oversized run
-                if (gt != 0ull) e2 = (uint32_t)(wq * 64 + __builtin_ctzll(gt));
-                else if (Cw != 0ull) e2 = (uint32_t)((wq + 1) * 64 + __builtin_ctzll(Cw));
-                else in_big = true;
                 pk[q] = slot[p];
-                if (in_big || e2 - s > (uint32_t)RK_BIG) {
-                    res[r0 + q] = pk[q];  // the all-equal pass left pixel << 14 | rank in the slots of oversized buckets
-                } else if (e2 - s > (uint32_t)R2_TMAX) {
+                // bucket starts among the slots lo .. lo + 13 around p (lo = p - 6): runs of <= R2_TMAX = 6 slots have
+                // both ends inside this 14-bit window; everything longer is ranked by the one-per-thread pass
+                const int lo = p > 6 ? p - 6 : 0, d = p - lo;
+                const int wi = lo >> 5;
+                const unsigned long long two = (unsigned long long)bs[wi] | ((unsigned long long)bs[wi + 1] << 32);
+                const uint32_t win = (uint32_t)(two >> (lo & 31));                 // bit i: slot lo + i starts a run
+                const uint32_t below = win & ((2u << d) - 1u);                     // starts at lo .. p
+                const uint32_t above = (win >> (d + 1)) & 0x7fu;                   // starts at p + 1 .. p + 7
+                bool in_big = false;  // the all-equal pass left pixel << 14 | rank in the slots of oversized buckets
+                for (unsigned bi = 0; bi < nbig; bi++) in_big = in_big || ((uint32_t)p - misc[2 + 2 * bi] < misc[3 + 2 * bi]);
+                const uint32_t s = (uint32_t)(lo + 31 - __clz(below | 0u)), e2 = (uint32_t)(p + 1 + __builtin_ctz(above | 0x80u));
+                if (in_big) {
+                    res[r0 + q] = pk[q];
+                } else if (below == 0u || above == 0u || e2 - s > (uint32_t)R2_TMAX) {
                     const uint32_t qi = atomicAdd(&misc[20], 1u);  // long run: one-per-thread pass
                     if (qi < (uint32_t)QCAP) queue[qi] = (uint32_t)p;
                 } else {
