@@ -30,7 +30,10 @@ constexpr int R2_IDX_BITS = 14;  // pixel index inside a column, n <= 16384
 constexpr uint32_t R2_IDX_MASK = (1u << R2_IDX_BITS) - 1u;
 constexpr int R2_SUB_BITS = 18;
 constexpr uint32_t R2_NONE = 0xffffffffu;
-constexpr int R2_TMAX = 6;       // runs longer than this are ranked one slot per thread (6d), not in the G-wide loop
+#ifndef R2_TMAX_VALUE
+#define R2_TMAX_VALUE 6
+#endif
+constexpr int R2_TMAX = R2_TMAX_VALUE;  // runs longer than this are ranked one slot per thread (6d), not in the G-wide loop
 
 template <int ITEMS>
 struct R2 {
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         klo = red[k] < klo ? red[k] : klo;
         khi = red[16 + k] > khi ? red[16 + k] : khi;
     }
-    __syncthreads();  // red is reused by the scans
+    // (red is next written by the scan of step 5, two barriers from here)
     if (khi >= 0xff800000u || klo <= 0x007fffffu) {  // non-finite keys cannot be bucketed by value: radix kernel
         if (tid == 0) a.flags[col] = 1;
         return;
@@ -170,18 +173,27 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     __syncthreads();
     SORT_PROBE(2);
-    // ---- 3. equalisation: coarse bin b gets w_b = 1 + cnt_b * NB / nsamp fine buckets
-    {
-        unsigned q = 0;
-        if (tid < RK_COARSE) {
-            const unsigned x = c1[tid] * (unsigned)NB;  // < 2^27: exact quotient via a float estimate + one correction
-            q = (unsigned)((float)x / (float)nsamp);
+    // ---- 3. equalisation: coarse bin b gets w_b = 1 + cnt_b * NB / nsamp fine buckets.  One wavefront, four bins per
+    //         lane: no block-wide scan, one barrier
+    if (w == 0) {
+        const uint4 c = *reinterpret_cast<const uint4*>(c1 + 4 * lane);
+        auto width = [&](unsigned cnt) {
+            const unsigned x = cnt * (unsigned)NB;  // < 2^27: exact quotient via a float estimate + one correction
+            unsigned q = (unsigned)((float)x / (float)nsamp);
             if (q * nsamp > x) q--;
             else if ((q + 1u) * nsamp <= x) q++;
+            return 1u + q;
+        };
+        const unsigned w0 = width(c.x), w1 = width(c.y), w2 = width(c.z), w3 = width(c.w);
+        const unsigned sum = w0 + w1 + w2 + w3;
+        unsigned incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
         }
-        const unsigned wd = tid < RK_COARSE ? 1u + q : 0u;
-        const unsigned base = block_excl_scan(wd, red, nullptr);
-        if (tid < RK_COARSE) c1[tid] = base | (wd << 16);
+        const unsigned b0 = incl - sum, b1 = b0 + w0, b2 = b1 + w1, b3 = b2 + w2;
+        *reinterpret_cast<uint4*>(c1 + 4 * lane) = make_uint4(b0 | (w0 << 16), b1 | (w1 << 16), b2 | (w2 << 16), b3 | (w3 << 16));
     }
     __syncthreads();
     SORT_PROBE(3);
@@ -328,17 +340,17 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             res[r0 + q] = R2_NONE;
             if (p < n) {
                 pk[q] = slot[p];
-                // bucket starts among the slots lo .. lo + 13 around p (lo = p - 6): runs of <= R2_TMAX = 6 slots have
-                // both ends inside this 14-bit window; everything longer is ranked by the one-per-thread pass
-                const int lo = p > 6 ? p - 6 : 0, d = p - lo;
+                // bucket starts among the slots lo .. lo + 2 T + 1 around p (lo = p - T, T = R2_TMAX): runs of <= T slots
+                // have both ends inside this window; everything longer is ranked by the one-per-thread pass
+                const int lo = p > R2_TMAX ? p - R2_TMAX : 0, d = p - lo;
                 const int wi = lo >> 5;
                 const unsigned long long two = (unsigned long long)bs[wi] | ((unsigned long long)bs[wi + 1] << 32);
                 const uint32_t win = (uint32_t)(two >> (lo & 31));                 // bit i: slot lo + i starts a run
                 const uint32_t below = win & ((2u << d) - 1u);                     // starts at lo .. p
-                const uint32_t above = (win >> (d + 1)) & 0x7fu;                   // starts at p + 1 .. p + 7
+                const uint32_t above = (win >> (d + 1)) & ((2u << R2_TMAX) - 1u);  // starts at p + 1 .. p + R2_TMAX + 1
                 bool in_big = false;  // the all-equal pass left pixel << 14 | rank in the slots of oversized buckets
                 for (unsigned bi = 0; bi < nbig; bi++) in_big = in_big || ((uint32_t)p - misc[2 + 2 * bi] < misc[3 + 2 * bi]);
-                const uint32_t s = (uint32_t)(lo + 31 - __clz(below | 0u)), e2 = (uint32_t)(p + 1 + __builtin_ctz(above | 0x80u));
+                const uint32_t s = (uint32_t)(lo + 31 - __clz(below | 0u)), e2 = (uint32_t)(p + 1 + __builtin_ctz(above | (2u << R2_TMAX)));
                 if (in_big) {
                     res[r0 + q] = pk[q];
                 } else if (below == 0u || above == 0u || e2 - s > (uint32_t)R2_TMAX) {
@@ -430,7 +442,10 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     //         into the slot array (every slot has been read: barrier), leave with 16-byte stores
     __syncthreads();
     float* val = reinterpret_cast<float*>(slot);
-    constexpr int FCH = 8;  // loads of a chunk are all in flight before the first LDS write waits for one
+    // the first queued result of this thread: its LDS read -> global read chain starts before the main loads
+    const uint32_t qr = (uint32_t)tid < qn ? queue[tid] : R2_NONE;
+    const float qv = ssrt[quantile_index(qr != R2_NONE ? (qr & R2_IDX_MASK) : 0u, ns, (unsigned)n, a.inv_2nt)];
+    constexpr int FCH = 16;  // loads of a chunk are all in flight before the first LDS write waits for one
 #pragma unroll
     for (int k0 = 0; k0 < ITEMS; k0 += FCH) {
         float v[FCH];
@@ -443,7 +458,8 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (int k = k0; k < k0 + FCH && k < ITEMS; k++)
             if (res[k] != R2_NONE) val[res[k] >> R2_IDX_BITS] = v[k - k0];
     }
-    for (uint32_t i = tid; i < qn; i += SORT_NT) {  // each thread reads back the entries it wrote
+    if (qr != R2_NONE) val[qr >> R2_IDX_BITS] = qv;
+    for (uint32_t i = tid + SORT_NT; i < qn; i += SORT_NT) {  // each thread reads back the entries it wrote
         const uint32_t r = queue[i];
         val[r >> R2_IDX_BITS] = ssrt[quantile_index(r & R2_IDX_MASK, ns, (unsigned)n, a.inv_2nt)];
     }
