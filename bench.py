@@ -172,6 +172,14 @@ def main():
     ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
     args = ap.parse_args()
 
+    rank_env, world_env, _ = otdist.env_world()
+    if world_env > 1:
+        # one MIOpen find-db / kernel cache per rank: eight processes tuning the same convolution shapes at once would
+        # otherwise contend for one sqlite file under ~/.config/miopen
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/optex_miopen_db_rank{rank_env}")
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/optex_miopen_cache_rank{rank_env}")
+        for d in (os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_CUSTOM_CACHE_DIR"]):
+            os.makedirs(d, exist_ok=True)
     rank, world, device = otdist.init_distributed()
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
