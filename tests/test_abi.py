@@ -39,6 +39,14 @@ def test_argument_errors_are_reported_without_launching():
     assert rc == -1 and b"optex_gemm_tn" in lib.optex_last_error()
     rc = lib.optex_rotations_from_normals(None, 1, 1, None, None, None, None, None)
     assert rc == -1
+    # glue: pool and upsample are exclusive; NHWC on both sides needs C % 4 == 0 (both rejected before any launch)
+    import ctypes
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.optex_vgg_glue_layout(ptr, None, ptr, 1, 4, 2, 2, 0, 1, 1, 0, 1, 1, None) == -1
+    assert b"optex_vgg_glue_layout" in lib.optex_last_error()
+    assert lib.optex_vgg_glue_layout(ptr, None, ptr, 1, 3, 4, 4, 0, 0, 0, 0, 1, 1, None) != 0
+    assert b"C % 4" in lib.optex_last_error()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
