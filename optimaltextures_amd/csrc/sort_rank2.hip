@@ -38,7 +38,9 @@ constexpr int R2_TMAX = R2_TMAX_VALUE;  // runs longer than this are ranked one 
 template <int ITEMS>
 struct R2 {
     static constexpr int CAP = ITEMS * SORT_NT;
-    static constexpr int NB = ITEMS == 16 ? CAP * 3 / 8 : CAP / 2;   // fine buckets handed out by the equalisation (16: what 80 KiB allow)
+    // fine buckets handed out by the equalisation: as many as 80 KiB of LDS (16 keys per thread) and the 13-bit bucket id
+    // allow — fewer keys per bucket = fewer compare trips and fewer queued slots
+    static constexpr int NB = ITEMS == 16 ? CAP * 3 / 8 : (ITEMS == 12 ? CAP * 5 / 8 : (ITEMS == 8 ? CAP * 15 / 16 : CAP));
     static constexpr int NBT = NB + RK_COARSE;                       // + 1 per coarse bin; even; < 2^13
     static constexpr int NW2 = NBT / 2;                              // packed u16 counters
     static constexpr int PER = (NW2 + SORT_NT - 1) / SORT_NT;
