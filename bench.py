@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused", help="one extra step each (N = 1 only); 'fused' = the re-associated rotation fast path")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
+    ap.add_argument("--no_miopen_find", action="store_true", help="torch.backends.cudnn.benchmark = False: MIOpen picks the convolution kernels from its heuristics / find-db instead of timing every solver in the warm-up step")
     args = ap.parse_args()
 
     rank_env, world_env, _ = otdist.env_world()
@@ -185,7 +186,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode: the VGG convs are the largest non-hot-path cost
+    torch.backends.cudnn.benchmark = not args.no_miopen_find  # MIOpen find mode: the VGG convs are the largest non-hot-path cost
 
     B = args.batch
     style = synthetic_style(device)
