@@ -185,24 +185,23 @@ class OptimalTexture(torch.nn.Module):
         self.rng = None         # numpy RandomState for the rotations (None = numpy's global state, like the reference)
 
     # -- optex.py:45-79, channel-major
-    def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int):
-        if pastiche.shape[-2] != size and pastiche.shape[-1] != size:
-            style_tens = [resize(s, size=get_size(size, self.style_scale, s.shape[2], s.shape[3])) for s in styles]
-            if content is not None:
-                cont_size = get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True)
-                cont_tens = resize(content, size=cont_size)
-            else:
-                cont_size, cont_tens = (size, size), None
-            pastiche = resize(pastiche, size=cont_size)
-        else:
-            style_tens, cont_tens = styles, content
+    def _needs_resize(self, hw, size: int) -> bool:
+        return hw[0] != size and hw[1] != size  # the reference resizes only if BOTH sides differ (optex.py:47)
 
-        style_features, style_eigvs, content_features, style_hw = [], [], [], []
+    def _style_tensors(self, styles: List[Tensor], size: int, resized: bool):
+        if not resized:
+            return styles
+        return [resize(s, size=get_size(size, self.style_scale, s.shape[2], s.shape[3])) for s in styles]
+
+    def _style_side(self, style_tens: Optional[List[Tensor]]):
+        """per encoder: style features [n_styles, k, Hs*Ws] (channel-major), PCA basis, feature-map size.  With a
+        style_sync hook only its source rank encodes / fits; everyone receives the result (dist.StyleSync)."""
+        style_features, style_eigvs, style_hw = [], [], []
         for encoder in self.encoders:
-            payload = None
+            payload, hw = None, None
             if self.style_sync is None or self.style_sync.is_source:
                 sf = torch.cat([encoder.features(s) for s in style_tens])  # [n_styles, C, Hs, Ws]
-                hw = sf.shape[2:]
+                hw = (int(sf.shape[2]), int(sf.shape[3]))
                 sf = sf.reshape(sf.shape[0], sf.shape[1], -1)
                 if self.use_pca:
                     sf, eigvecs = fit_pca_cm(sf)
@@ -211,11 +210,52 @@ class OptimalTexture(torch.nn.Module):
                 payload = [sf.contiguous(), eigvecs, torch.tensor(list(hw), device=sf.device, dtype=torch.float32)]
             if self.style_sync is not None:
                 payload = self.style_sync(payload)
-            sf, eigvecs, hw = payload
+            sf, eigvecs, hw_t = payload
+            if hw is None:  # received: the size travels with the payload
+                hw = (int(hw_t[0].item()), int(hw_t[1].item()))
             style_features.append(sf)
             style_eigvs.append(eigvecs)
-            style_hw.append((int(hw[0].item()), int(hw[1].item())))
-            if cont_tens is not None:
+            style_hw.append(hw)
+        return style_features, style_eigvs, style_hw
+
+    def prefetch_style_sides(self, pastiche_hw, styles: List[Tensor], content: Optional[Tensor]):
+        """The style side of EVERY pass, before the first one starts.  It depends on the pastiche only through its
+        size, which is known in advance (each pass leaves the pastiche at its content size).  With a style_sync hook this
+        puts all broadcasts — and the host synchronisations that learning the PCA shapes costs the receiving ranks — at
+        the start of a forward call instead of one per pass in the middle of the receivers' kernel queues."""
+        hw, sides = (int(pastiche_hw[0]), int(pastiche_hw[1])), []
+        for p in range(self.passes):
+            size = self.sizes[p]
+            resized = self._needs_resize(hw, size)
+            need = self.style_sync is None or self.style_sync.is_source
+            sides.append((resized,) + self._style_side(self._style_tensors(styles, size, resized) if need else None))
+            if resized:
+                hw = (get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True) if content is not None
+                      else (size, size))
+        return sides
+
+    def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int,
+                      style_side=None):
+        resized = self._needs_resize(pastiche.shape[-2:], size)
+        if resized:
+            if content is not None:
+                cont_size = get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True)
+                cont_tens = resize(content, size=cont_size)
+            else:
+                cont_size, cont_tens = (size, size), None
+            pastiche = resize(pastiche, size=cont_size)
+        else:
+            cont_tens = content
+        if style_side is not None and style_side[0] == resized:
+            style_side = style_side[1:]
+        else:  # no prefetch, or the pastiche did not have the predicted size (same on every rank: shapes are global)
+            need = self.style_sync is None or self.style_sync.is_source
+            style_side = self._style_side(self._style_tensors(styles, size, resized) if need else None)
+        style_features, style_eigvs, style_hw = style_side
+
+        content_features = []
+        if cont_tens is not None:
+            for encoder, sf, eigvecs in zip(self.encoders, style_features, style_eigvs):
                 cf = encoder.features(cont_tens)
                 cf = cf.reshape(cf.shape[0], cf.shape[1], -1)
                 if self.use_pca:
@@ -225,11 +265,13 @@ class OptimalTexture(torch.nn.Module):
         return pastiche, style_features, style_eigvs, content_features, style_hw
 
     def forward(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor] = None, verbose: bool = False):
+        # multi-GPU: all style broadcasts of this call up front (see prefetch_style_sides); single GPU: pass by pass
+        sides = self.prefetch_style_sides(pastiche.shape[-2:], styles, content) if self.style_sync is not None else None
         for p in range(self.passes):
             if verbose:
                 print(f"Pass {p}, size {self.sizes[p]}")
             pastiche, style_features, style_eigvs, content_features, style_hw = self.encode_inputs(
-                pastiche, styles, content, self.sizes[p])
+                pastiche, styles, content, self.sizes[p], style_side=sides[p] if sides is not None else None)
 
             if len(styles) > 1:
                 # the reference sizes the mask on the relu4_1 grid (style_features[1], optex.py:98-99)

@@ -856,6 +856,43 @@ def test_config3_style_transfer_1024_runs(dev):
     assert bool(torch.isfinite(plain).all()) and float((out - plain).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("no_pca,with_content", [(True, False), (False, True)])
+def test_driver_style_prefetch_equals_pass_by_pass(dev, no_pca, with_content):
+    """Multi-GPU runs compute / broadcast the style side of every pass at the start of forward() (driver.py
+    prefetch_style_sides).  With a pass-through sync hook (world size 1): the prefetched style sides are the ones the
+    pass-by-pass path computes (same resize decisions, same feature-map sizes, same PCA rank; values up to the fp32
+    noise of MIOpen's convolutions, whose kernel choice and summation order are not fixed across calls), and a forward
+    call through the hook runs to a finite image of the right shape.  (A whole-image comparison is meaningless: the cdf
+    map is discontinuous, so convolution round-off noise grows to O(1) over the iterations.)"""
+    from optimaltextures_amd import dist as otdist
+    from optimaltextures_amd.driver import OptimalTexture
+    tex = OptimalTexture(size=320, iters=30, passes=3, hist_mode="cdf", no_pca=no_pca, layers=(3, 2),
+                         content_strength=0.2, independent=not with_content).to(dev).eval()
+    style = _smooth_image(200, 264, 11).to(dev)
+    content = _smooth_image(288, 352, 12).to(dev) if with_content else None
+    noise = torch.rand((1 if with_content else 3, 3, 320, 320), generator=torch.Generator().manual_seed(13)).to(dev)
+    with torch.inference_mode():
+        tex.style_sync = otdist.StyleSync(dev)
+        sides = tex.prefetch_style_sides(noise.shape[-2:], [style], content)
+        tex.style_sync = None
+        pastiche = noise.clone()
+        for p in range(tex.passes):
+            resized = tex._needs_resize(pastiche.shape[-2:], tex.sizes[p])
+            assert sides[p][0] == resized
+            pastiche, sf, eig, cf, hw = tex.encode_inputs(pastiche, [style], content, tex.sizes[p])
+            assert hw == sides[p][3]
+            for got, want in zip(sides[p][1], sf):
+                assert got.shape == want.shape
+                if no_pca:  # with PCA the basis vectors are only defined up to sign / rotation inside near-equal values
+                    assert torch.allclose(got, want, rtol=0, atol=1e-4 * float(want.abs().max()))
+            for got, want in zip(sides[p][2], eig):
+                assert got.shape == want.shape
+        tex.style_sync = otdist.StyleSync(dev)
+        tex.rng = np.random.RandomState(14)
+        out = tex.forward(noise.clone(), [style], content)
+    assert out.shape[-2:] == pastiche.shape[-2:] and out.shape[0] == noise.shape[0] and bool(torch.isfinite(out).all())
+
+
 def test_config5_two_style_mixing_runs(dev):
     """BASELINE config 5 at reduced size: two-style mixing (optex.py:97-101,193-206) over relu3_1..relu1_1 with PCA,
     hist_mode cdf — the un-rotated hist_match calls of mix_style_features go through the same boundary"""
