@@ -118,3 +118,30 @@ def test_sharded_textures_equal_single_process():
     assert sorted(two[0]) == [0, 1, 2] and sorted(two[1]) == [3, 4]
     for i in range(5):
         assert np.array_equal(merged[i], one[0][i])              # sharding changes nothing, bit for bit
+
+
+# ------------------------------------------------------------------------------------------------ style prefetch of the driver
+def _prefetch_job(rank, world, device):
+    """driver.OptimalTexture.prefetch_style_sides over gloo: rank 0 encodes the style for every pass (torch-CPU VGG,
+    no_pca so that no HIP kernel is involved), rank 1 only receives."""
+    from optimaltextures_amd.driver import OptimalTexture
+    torch.manual_seed(0)
+    tex = OptimalTexture(size=288, iters=10, passes=2, hist_mode="cdf", no_pca=True, layers=(1,)).eval()
+    tex.style_sync = otdist.StyleSync(device)
+    g = torch.Generator().manual_seed(5)
+    style = torch.rand(1, 3, 96, 128, generator=g) if tex.style_sync.is_source else torch.zeros(1, 3, 96, 128)
+    with torch.inference_mode():
+        sides = tex.prefetch_style_sides((288, 288), [style], None)
+    return [(bool(r), [f.numpy().copy() for f in sf], [tuple(e.shape) for e in eig], list(hw)) for r, sf, eig, hw in sides]
+
+
+def test_driver_style_prefetch_gloo_world2():
+    res = run_world(_prefetch_job, 2)
+    a, b = res[0], res[1]
+    assert len(a) == len(b) == 2                                   # one entry per pass
+    assert [x[0] for x in a] == [x[0] for x in b] == [True, True]   # 288 -> 256 for pass 0, 256 -> 288 for pass 1
+    for (ra, fa, ea, ha), (rb, fb, eb, hb) in zip(a, b):
+        assert ha == hb and ea == eb == [(0, 0)]
+        for x, y in zip(fa, fb):
+            assert x.shape == y.shape and x.shape[1] == 64 and np.array_equal(x, y)   # rank 1 holds rank 0's features
+    assert a[0][1][0].shape[2] == a[0][3][0][0] * a[0][3][0][1]      # [1, C, Hs * Ws] and its (Hs, Ws)
