@@ -15,6 +15,9 @@
  *    (`ws`, sized by the *_ws_bytes helpers) and every call is asynchronous on `stream` (a hipStream_t;
  *    NULL = the legacy default stream).  Calls are therefore stream-ordered, re-entrant and capturable
  *    in a hipGraph.
+ *  - Every `void* ws` is followed by `size_t ws_bytes`, the size of the buffer the caller really owns: a call
+ *    whose scratch is smaller than its *_ws_bytes helper asks for returns OPTEX_E_ARG before anything is
+ *    enqueued (ABI 3; ABI 2 trusted the pointer).
  *  - Feature tensors are "channel-major segments": segment s (one independent texture), channel c,
  *    pixel i lives at  base + s*seg_stride + c*ld + i  (fp32 elements).  NCHW-contiguous memory is
  *    (ld = H*W, seg_stride = C*H*W); the reference's pooled layout hist.view(c, -1) (histmatch.py:11,17)
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 2
+#define OPTEX_ABI_VERSION 3
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -84,7 +87,7 @@ size_t optex_cdf_ws_bytes(int C, int n_seg);
 int optex_cdf_match(const float* target, long ldt, long t_seg_stride, long nt,
                     const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
                     int C, int n_seg, float* out, long ldo, long o_seg_stride,
-                    void* ws, float* dbg, void* stream);
+                    void* ws, size_t ws_bytes, float* dbg, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K6  sort mode — exact 1-D optimal transport per rotated column (north-star addition; there
@@ -94,13 +97,13 @@ int optex_cdf_match(const float* target, long ldt, long t_seg_stride, long nt,
 size_t optex_sort_ws_bytes(long n, int C, int n_seg);
 /* keys -> out_keys [n_seg, C, n] and out_idx [n_seg, C, n] uint32 (either may be NULL) */
 int optex_sort_columns(const float* keys, long ld, long seg_stride, long n, int C, int n_seg, float* out_keys,
-                       uint32_t* out_idx, void* ws, void* stream);
+                       uint32_t* out_idx, void* ws, size_t ws_bytes, void* stream);
 size_t optex_sort_match_ws_bytes(long nt, long ns, int C, int n_seg, int src_n_seg);
 /* out[rank_i] = sorted_source[floor((2i+1)*ns / (2*nt))] where rank_i is the pixel holding the i-th smallest
  * target value of the column. */
 int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt,
                      const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
-                     int C, int n_seg, float* out, long ldo, long o_seg_stride, void* ws, void* stream);
+                     int C, int n_seg, float* out, long ldo, long o_seg_stride, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K4  linear modes, histmatch.py:16-22: per-(segment, channel) spatial mean and the centred covariance
@@ -112,7 +115,7 @@ int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt,
  * ------------------------------------------------------------------------------------------------- */
 size_t optex_linear_stats_ws_bytes(long n, int C, int n_seg);
 int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool, float eps,
-                       float* mu, float* cov, void* ws, void* stream);
+                       float* mu, float* cov, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * R0  rotation generator, optex.py:142-149 -> scipy.stats.special_ortho_group.rvs (Householder chain, fp64).
@@ -124,7 +127,7 @@ int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, 
 long optex_rotation_normals(int N);
 size_t optex_rotation_ws_bytes(int N, int count);
 int optex_rotations_from_normals(const double* normals, int N, int count, double* R64, float* R32, float* Rt32,
-                                 void* ws, void* stream);
+                                 void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fused hot loop, optex.py:112-117 for the modes that need no host-side factorization (cdf, sort):
@@ -141,7 +144,7 @@ size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int s
                               int fuse_rotations);
 int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
                   const float* R32, const float* Rt32, int iters, const float* content, float strength,
-                  int fuse_rotations, void* ws, void* stream);
+                  int fuse_rotations, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * N3  element-wise glue between the VGG convolutions, vgg.py:14-135: conv bias add, nn.ReLU,

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Command line of the MI355X build: same flags and defaults as the reference's optex.py:222-244, plus
---layers / --models_dir / --independent / --np_seed (extensions; the reference hard-codes all five layers, loads
-weights from ./models and leaves numpy's RNG — which drives the rotations — unseeded)."""
+--layers / --models_dir / --synthetic_weights / --independent / --np_seed (extensions; the reference hard-codes all five
+layers, loads weights from ./models and leaves numpy's RNG — which drives the rotations — unseeded).
+
+Paths are taken as given; a relative path that does not exist is looked up under this repository's assets/ directory
+(assets/style/graffiti.jpg, assets/models/...: the reference's data files, see assets/PROVENANCE.md), so the reference's
+own command lines (`python optex.py -s style/graffiti.jpg`) work unchanged."""
 import argparse
+import os
 from time import time
 
 import numpy as np
@@ -21,6 +26,17 @@ def required_length(nmin, nmax):
             setattr(args, self.dest, values)
 
     return RequiredLength
+
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def resolve(path):
+    """the path itself, or its counterpart under assets/ when only that exists"""
+    if path is None or os.path.exists(path) or os.path.isabs(path):
+        return path
+    alt = os.path.join(ROOT, "assets", path)
+    return alt if os.path.exists(alt) else path
 
 
 def build_parser():
@@ -49,6 +65,9 @@ def build_parser():
     # extensions
     p.add_argument("--layers", type=int, nargs="+", default=[5, 4, 3, 2, 1], help="VGG depths to run (reluN_1)")
     p.add_argument("--models_dir", type=str, default="models", help="directory with the pretrained .pth files")
+    p.add_argument("--synthetic_weights", action="store_true",
+                   help="depths whose .pth file is missing (relu4_1 / relu5_1 are absent from the reference repository) run "
+                        "with seeded random weights instead of raising FileNotFoundError")
     p.add_argument("--independent", action="store_true", help="--batch images are independent textures (not pooled)")
     p.add_argument("--np_seed", type=int, default=None, help="seed numpy's global RNG (drives the rotations)")
     return p
@@ -66,11 +85,16 @@ def main(argv=None):
     if args.np_seed is not None:
         np.random.seed(args.np_seed)
 
+    if world > 1 and args.independent and args.batch < world:
+        raise SystemExit(f"--independent --batch {args.batch} cannot be sharded over {world} ranks: every rank needs at "
+                         "least one texture (use --batch >= the number of GPUs)")
+    style_files, content_file = [resolve(s) for s in args.style], resolve(args.content)
+
     with torch.inference_mode():
-        styles = load_styles(args.style, size=args.size, scale=args.style_scale, device=device, memory_format=memory_format)
+        styles = load_styles(style_files, size=args.size, scale=args.style_scale, device=device, memory_format=memory_format)
         if len(styles) > 1:
             assert styles[0].shape == styles[1].shape, "Style images must have the same shape"
-        content = maybe_load_content(args.content, size=args.size, device=device, memory_format=memory_format)
+        content = maybe_load_content(content_file, size=args.size, device=device, memory_format=memory_format)
         lo, hi = otdist.shard_range(args.batch, rank, world) if (world > 1 and args.independent) else (0, args.batch)
         shape = content.shape if content is not None else (hi - lo, 3, args.size, args.size)
         pastiche = torch.rand(shape).to(device=device, memory_format=memory_format)
@@ -79,7 +103,11 @@ def main(argv=None):
             size=args.size, iters=args.iters, passes=args.passes, hist_mode=args.hist_mode,
             color_transfer=args.color_transfer, content_strength=args.content_strength, style_scale=args.style_scale,
             mixing_alpha=args.mixing_alpha, no_pca=args.no_pca, no_multires=args.no_multires, layers=args.layers,
-            models_dir=args.models_dir, independent=args.independent).to(device)
+            models_dir=resolve(args.models_dir), independent=args.independent,
+            allow_synthetic=args.synthetic_weights).to(device)
+        if rank == 0:
+            for enc, dec in zip(texturizer.encoders, texturizer.decoders):
+                print(f"relu{enc.depth}_1 weights: encoder {enc.weights} | decoder {dec.weights}")
         if world > 1:
             texturizer.style_sync = otdist.StyleSync(device)
 
@@ -90,7 +118,9 @@ def main(argv=None):
             print("Took:", time() - t)
     if world > 1:
         args.output_dir = f"{args.output_dir.rstrip('/')}/rank{rank}"
-    print("\n".join(save_image(pastiche, args)))
+    paths = save_image(pastiche, args)
+    print("\n".join(paths))
+    return paths
 
 
 if __name__ == "__main__":

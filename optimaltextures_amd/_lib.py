@@ -7,7 +7,7 @@ import torch  # imported BEFORE the CDLL so the library binds to the HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liboptex_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 CHANNEL_MAJOR, PIXEL_MAJOR = 0, 1
 
 _c = ctypes
@@ -23,18 +23,18 @@ SIGNATURES = {
     "optex_col_histc": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _P]),
     "optex_interp": (_I, [_P, _L, _P, _P, _L, _P, _P]),
     "optex_cdf_ws_bytes": (_SZ, [_I, _I]),
-    "optex_cdf_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _P, _P]),
+    "optex_cdf_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _P, _P]),
     "optex_sort_ws_bytes": (_SZ, [_L, _I, _I]),
-    "optex_sort_columns": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _P]),
+    "optex_sort_columns": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _SZ, _P]),
     "optex_sort_match_ws_bytes": (_SZ, [_L, _L, _I, _I, _I]),
-    "optex_sort_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _P]),
+    "optex_sort_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _P]),
     "optex_linear_stats_ws_bytes": (_SZ, [_L, _I, _I]),
-    "optex_linear_stats": (_I, [_P, _L, _L, _L, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "optex_linear_stats": (_I, [_P, _L, _L, _L, _I, _I, _I, _F, _P, _P, _P, _SZ, _P]),
     "optex_rotation_normals": (_L, [_I]),
     "optex_rotation_ws_bytes": (_SZ, [_I, _I]),
-    "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
+    "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "optex_ot_loop_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I]),
-    "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _I, _P, _F, _I, _P, _P]),
+    "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _I, _P, _F, _I, _P, _SZ, _P]),
     "optex_vgg_glue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "optex_vgg_glue_layout": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "optex_prof_enable": (_I, [_I]),

@@ -24,6 +24,15 @@ int check_launch(const char* what) {
     return OPTEX_OK;
 }
 
+int check_ws(const char* fn, const void* ws, size_t have, size_t need) {
+    if (need == 0) return OPTEX_OK;
+    if (!ws || have < need) {
+        set_error("%s: scratch buffer too small: ws_bytes = %zu, this call needs %zu (see the *_ws_bytes helper)", fn, have, need);
+        return OPTEX_E_ARG;
+    }
+    return OPTEX_OK;
+}
+
 int device_cu_count() {
     static thread_local int cached_dev = -1, cached_cu = 256;
     int dev = 0;

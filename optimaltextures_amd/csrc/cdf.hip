@@ -457,7 +457,7 @@ extern "C" size_t optex_cdf_ws_bytes(int C, int n_seg) { return CdfWs::bytes(C, 
 
 extern "C" int optex_cdf_match(const float* target, long ldt, long t_seg_stride, long nt, const float* source, long lds,
                                long s_seg_stride, long ns, int src_n_seg, int C, int n_seg, float* out, long ldo,
-                               long o_seg_stride, void* ws, float* dbg, void* stream) {
+                               long o_seg_stride, void* ws, size_t ws_bytes, float* dbg, void* stream) {
     if (!target || !source || !out || !ws || nt <= 0 || ns <= 0 || C <= 0 || n_seg <= 0 || ldt < nt || lds < ns ||
         ldo < nt) {
         set_error("optex_cdf_match: bad argument (nt=%ld ns=%ld C=%d n_seg=%d)", nt, ns, C, n_seg);
@@ -467,6 +467,7 @@ extern "C" int optex_cdf_match(const float* target, long ldt, long t_seg_stride,
         set_error("optex_cdf_match: source has %d segments, expected 1 or %d", src_n_seg, n_seg);
         return OPTEX_E_ARG;
     }
+    if (int rc = check_ws("optex_cdf_match", ws, ws_bytes, optex_cdf_ws_bytes(C, n_seg))) return rc;
     return cdf_match_impl(target, ldt, t_seg_stride, nt, source, lds, s_seg_stride, ns, src_n_seg, C, n_seg, out, ldo,
                           o_seg_stride, ws, dbg, as_stream(stream));
 }

@@ -171,11 +171,12 @@ extern "C" size_t optex_linear_stats_ws_bytes(long n, int C, int n_seg) {
 }
 
 extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool,
-                                  float eps, float* mu, float* cov, void* ws, void* stream) {
+                                  float eps, float* mu, float* cov, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !mu || !cov || !ws || n <= 0 || C <= 0 || n_seg <= 0 || ld < n) {
         set_error("optex_linear_stats: bad argument (n=%ld C=%d n_seg=%d ld=%ld)", n, C, n_seg, ld);
         return OPTEX_E_ARG;
     }
+    if (int rc = check_ws("optex_linear_stats", ws, ws_bytes, optex_linear_stats_ws_bytes(n, C, n_seg))) return rc;
     hipStream_t st = as_stream(stream);
     const int vec = aligned16(x) && ld % 4 == 0 && seg_stride % 4 == 0;
     {

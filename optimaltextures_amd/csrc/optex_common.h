@@ -16,6 +16,8 @@ constexpr int kNumXcd = 8;      // MI355X: 8 XCDs, block b is dispatched to XCD 
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// caller-owned scratch: refuse a buffer smaller than the *_ws_bytes helper asks for (include/optex.h, ABI 3)
+int check_ws(const char* fn, const void* ws, size_t have, size_t need);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

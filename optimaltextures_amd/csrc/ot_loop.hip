@@ -13,12 +13,13 @@ struct LoopWs {
     float* y2;   // second rotated buffer (fused rotations only: the re-rotation cannot run in place)
     float* P;    // [iters - 1, C, C] re-rotation matrices R_i^T R_{i+1} (fused rotations only)
     void* mode_ws;
-    static size_t mode_bytes(int mode, long ns, int C, int n_seg, int src_n_seg) {
-        return mode == 0 ? optex_cdf_ws_bytes(C, n_seg) : optex_sort_match_ws_bytes(0, ns, C, n_seg, src_n_seg);
+    static size_t mode_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg) {
+        // the sort scratch depends on BOTH column lengths: pastiche columns longer than one LDS take the global radix
+        return mode == 0 ? optex_cdf_ws_bytes(C, n_seg) : optex_sort_match_ws_bytes(n, ns, C, n_seg, src_n_seg);
     }
     static size_t bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters, int fused) {
         size_t b = align_up((size_t)n_seg * C * n * sizeof(float), 256) +
-                   align_up((size_t)src_n_seg * C * ns * sizeof(float), 256) + mode_bytes(mode, ns, C, n_seg, src_n_seg);
+                   align_up((size_t)src_n_seg * C * ns * sizeof(float), 256) + mode_bytes(mode, n, ns, C, n_seg, src_n_seg);
         if (fused)
             b += align_up((size_t)n_seg * C * n * sizeof(float), 256) +
                  align_up((size_t)(iters > 1 ? iters - 1 : 1) * C * C * sizeof(float), 256);
@@ -49,7 +50,7 @@ extern "C" size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n
 
 extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
                              const float* R32, const float* Rt32, int iters, const float* content, float strength,
-                             int fuse_rotations, void* ws, void* stream) {
+                             int fuse_rotations, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !style || !R32 || !Rt32 || !ws || n <= 0 || ns <= 0 || C < 2 || n_seg <= 0 || iters < 0) {
         set_error("optex_ot_loop: bad argument (n=%ld ns=%ld C=%d n_seg=%d iters=%d)", n, ns, C, n_seg, iters);
         return OPTEX_E_ARG;
@@ -66,6 +67,9 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         set_error("optex_ot_loop: fuse_rotations needs the un-rotated pastiche between iterations for the content blend");
         return OPTEX_E_ARG;
     }
+    if (int rc = check_ws("optex_ot_loop", ws, ws_bytes,
+                          optex_ot_loop_ws_bytes(mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations)))
+        return rc;
     LoopWs w(ws, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations);
     hipStream_t st = as_stream(stream);
     const long xs = (long)C * n, ss = (long)C * ns;

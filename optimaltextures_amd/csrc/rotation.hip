@@ -90,7 +90,7 @@ extern "C" size_t optex_rotation_ws_bytes(int N, int count) {
 }
 
 extern "C" int optex_rotations_from_normals(const double* normals, int N, int count, double* R64, float* R32,
-                                            float* Rt32, void* ws, void* stream) {
+                                            float* Rt32, void* ws, size_t ws_bytes, void* stream) {
     if (!normals || !ws || N < 2 || count <= 0) {
         set_error("optex_rotations_from_normals: Dimension of rotation must be specified, and must be a scalar greater "
                   "than 1 (N=%d count=%d)", N, count);
@@ -100,6 +100,7 @@ extern "C" int optex_rotations_from_normals(const double* normals, int N, int co
         set_error("optex_rotations_from_normals: N = %d > 1024 is not supported", N);
         return OPTEX_E_UNSUPPORTED;
     }
+    if (int rc = check_ws("optex_rotations_from_normals", ws, ws_bytes, optex_rotation_ws_bytes(N, count))) return rc;
     hipStream_t st = as_stream(stream);
     const long per = optex_rotation_normals(N);
     double* V = static_cast<double*>(ws);

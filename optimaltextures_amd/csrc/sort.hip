@@ -545,9 +545,9 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
     a.inv_2nt = 1.0 / (2.0 * (double)a.n);
     int rc;
     if (use_rank) {
-        static thread_local bool attr_rank = false;
+        static DeviceOnce attr_rank;
         auto rkern = rank_columns_kernel<ITEMS, MODE>;
-        if ((rc = set_lds(rkern, rank_lds_bytes<ITEMS>(MODE == SORT_MATCH), &attr_rank))) return rc;
+        if ((rc = set_lds(rkern, rank_lds_bytes<ITEMS>(MODE == SORT_MATCH), attr_rank.slot()))) return rc;
         hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)ncols, st);
         if (e != hipSuccess) {
             set_error("sort: memset failed: %s", hipGetErrorString(e));
@@ -564,9 +564,9 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
         if ((rc = check_launch("rank_columns_kernel"))) return rc;
     }
     const size_t lds = (size_t)ITEMS * SORT_NT * 8 + (size_t)SORT_CSTR * SORT_NW * 4 + SORT_NW * 4;
-    static thread_local bool attr_radix = false;
+    static DeviceOnce attr_radix;
     auto kern = sort_columns_kernel<ITEMS, MODE>;
-    if ((rc = set_lds(kern, lds, &attr_radix))) return rc;
+    if ((rc = set_lds(kern, lds, attr_radix.slot()))) return rc;
     a.only_flagged = use_rank ? 1 : 0;
     // when it only sweeps up flagged columns the radix launch is accounted with zero algorithmic bytes
     ProfScope prof(use_rank ? KC_SORT_FALLBACK : (MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH), st, 0.0,
@@ -617,11 +617,12 @@ extern "C" size_t optex_sort_ws_bytes(long n, int C, int n_seg) {
 }
 
 extern "C" int optex_sort_columns(const float* keys, long ld, long seg_stride, long n, int C, int n_seg,
-                                  float* out_keys, uint32_t* out_idx, void* ws, void* stream) {
+                                  float* out_keys, uint32_t* out_idx, void* ws, size_t ws_bytes, void* stream) {
     if (!keys || n <= 0 || C <= 0 || n_seg <= 0 || ld < n) {
         set_error("optex_sort_columns: bad argument (n=%ld C=%d n_seg=%d ld=%ld)", n, C, n_seg, ld);
         return OPTEX_E_ARG;
     }
+    if (int rc = check_ws("optex_sort_columns", ws, ws_bytes, optex_sort_ws_bytes(n, C, n_seg))) return rc;
     SortArgs a{};
     a.keys = keys; a.ld = ld; a.ss = seg_stride; a.n = n; a.C = C; a.x_n_seg = n_seg;
     a.out_keys = out_keys; a.out_idx = out_idx;
@@ -640,7 +641,7 @@ extern "C" size_t optex_sort_match_ws_bytes(long nt, long ns, int C, int n_seg, 
 
 extern "C" int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt, const float* source,
                                 long lds, long s_seg_stride, long ns, int src_n_seg, int C, int n_seg, float* out,
-                                long ldo, long o_seg_stride, void* ws, void* stream) {
+                                long ldo, long o_seg_stride, void* ws, size_t ws_bytes, void* stream) {
     if (!target || !source || !out || !ws || nt <= 0 || ns <= 0 || C <= 0 || n_seg <= 0 || ldt < nt || lds < ns ||
         ldo < nt) {
         set_error("optex_sort_match: bad argument (nt=%ld ns=%ld C=%d n_seg=%d)", nt, ns, C, n_seg);
@@ -650,6 +651,7 @@ extern "C" int optex_sort_match(const float* target, long ldt, long t_seg_stride
         set_error("optex_sort_match: source has %d segments, expected 1 or %d", src_n_seg, n_seg);
         return OPTEX_E_ARG;
     }
+    if (int rc = check_ws("optex_sort_match", ws, ws_bytes, optex_sort_match_ws_bytes(nt, ns, C, n_seg, src_n_seg))) return rc;
     return sort_match_impl(target, ldt, t_seg_stride, nt, source, lds, s_seg_stride, ns, src_n_seg, C, n_seg, out, ldo,
                            o_seg_stride, ws, as_stream(stream));
 }

@@ -18,6 +18,17 @@ constexpr int RK_MIN_N = 512;            // shorter columns go straight to the r
 
 enum SortMode { SORT_EMIT = 0, SORT_MATCH = 1 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember it per device, so a
+// process that drives several GPUs sets it on each (a benign race: the call is idempotent).
+struct DeviceOnce {
+    bool done[64] = {};
+    bool* slot() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return &done[d & 63];
+    }
+};
+
 struct SortArgs {
     const float* keys; long ld, ss; long n; int C; int x_n_seg;
     float* out_keys; uint32_t* out_idx;                       // SORT_EMIT, contiguous [n_seg, C, n]

@@ -488,7 +488,8 @@ static int launch_rank_match_items(SortArgs a, int ncols, hipStream_t st) {
     hipError_t e;
     if (in_vec) {
         auto kern = rank_match_kernel<ITEMS, (ITEMS >= 4)>;
-        static thread_local bool attr = false;
+        static DeviceOnce once;
+        bool& attr = *once.slot();
         if (!attr) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return OPTEX_E_LAUNCH; }
@@ -497,7 +498,8 @@ static int launch_rank_match_items(SortArgs a, int ncols, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(ncols), dim3(SORT_NT), lds, st, a);
     } else {
         auto kern = rank_match_kernel<ITEMS, false>;
-        static thread_local bool attr = false;
+        static DeviceOnce once;
+        bool& attr = *once.slot();
         if (!attr) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return OPTEX_E_LAUNCH; }

@@ -159,14 +159,15 @@ def _pooled_iterations(x, style, hist_mode, R32, Rt32, content, strength):
 # ------------------------------------------------------------------------------------------------ OptimalTexture
 class OptimalTexture(torch.nn.Module):
     """Same constructor arguments and defaults as the reference (optex.py:16-28) plus extensions:
-    layers (VGG depths to run, deepest first; the reference hard-codes 5..1), models_dir (pretrained weights),
-    independent (batch = independent textures instead of one pooled distribution)."""
+    layers (VGG depths to run, deepest first; the reference hard-codes 5..1), models_dir (pretrained weights; None =
+    seeded synthetic weights), allow_synthetic (depths whose .pth file is missing get synthetic weights instead of
+    raising), independent (batch = independent textures instead of one pooled distribution)."""
 
     def __init__(self, size: int = 512, iters: int = 500, passes: int = 5, hist_mode: str = "chol",
                  color_transfer: Optional[str] = None, content_strength: float = 0.1, style_scale: float = 1,
                  mixing_alpha: float = 0.5, no_pca: bool = False, no_multires: bool = False,
                  layers=(5, 4, 3, 2, 1), models_dir: Optional[str] = None, independent: bool = False,
-                 fuse_rotations: bool = False):
+                 fuse_rotations: bool = False, allow_synthetic: bool = False, index_by_position: bool = False):
         super().__init__()
         self.hist_mode = hist_mode
         self.color_transfer = color_transfer
@@ -179,8 +180,12 @@ class OptimalTexture(torch.nn.Module):
         self.passes = passes
         self.iters_per_pass_and_layer, self.sizes = get_iters_and_sizes(size, iters, passes, not no_multires)
         self.layers = tuple(sorted({int(l) for l in layers}, reverse=True))
-        self.encoders = torch.nn.ModuleList([Encoder(l, models_dir) for l in self.layers])
-        self.decoders = torch.nn.ModuleList([Decoder(l, models_dir) for l in self.layers])
+        self.encoders = torch.nn.ModuleList([Encoder(l, models_dir, allow_synthetic) for l in self.layers])
+        self.decoders = torch.nn.ModuleList([Decoder(l, models_dir, allow_synthetic) for l in self.layers])
+        # The reference indexes its schedule and its content blend by the POSITION l of an encoder in its list
+        # (optex.py:112-117); with its hard-coded five-encoder list position == 5 - depth, which is what a subset of
+        # layers keeps by default.  index_by_position=True reproduces a reference whose list holds only `layers`.
+        self.index_by_position = index_by_position
         self.style_sync = None  # multi-GPU hook: callable(list of tensors or None) -> list of tensors (dist.py)
         self.rng = None         # numpy RandomState for the rotations (None = numpy's global state, like the reference)
 
@@ -276,13 +281,15 @@ class OptimalTexture(torch.nn.Module):
             if len(styles) > 1:
                 # the reference sizes the mask on the relu4_1 grid (style_features[1], optex.py:98-99)
                 ref = min(1, len(style_hw) - 1)
-                mask = torch.ceil(torch.rand(style_hw[ref], device=pastiche.device) - self.mixing_alpha)[None, None]
+                # drawn from torch's CPU generator (then moved): torch.manual_seed reproduces the reference CPU path's mask
+                mask = torch.ceil(torch.rand(style_hw[ref]) - self.mixing_alpha)[None, None].to(pastiche.device)
                 nhwc = [sf.view(sf.shape[0], sf.shape[1], *hw).permute(0, 2, 3, 1) for sf, hw in zip(style_features, style_hw)]
                 mixed = mix_style_features(nhwc, mask, self.mixing_alpha, self.hist_mode)
                 style_features = [to_nchw(m).reshape(1, m.shape[-1], -1).contiguous() for m in mixed]
 
             for li, (encoder, decoder) in enumerate(zip(self.encoders, self.decoders)):
-                enc_index = 5 - encoder.depth  # position in the reference's encoder list (0 = relu5_1)
+                # position in the reference's encoder list (0 = relu5_1 in the full list)
+                enc_index = li if self.index_by_position else 5 - encoder.depth
                 if verbose:
                     print(f"Layer: relu{encoder.depth}_1")
                 feat = encoder.features(pastiche)

@@ -102,7 +102,7 @@ def cdf_match_seg(t: Seg, s: Seg, out: Seg = None, debug=False):
     ws = workspace(lib.optex_cdf_ws_bytes(t.C, t.S), t.t.device)
     dbg = torch.empty((t.S, t.C, 2 + 4 * BINS), dtype=torch.float32, device=t.t.device) if debug else None
     check(lib.optex_cdf_match(ptr(t.t), t.ld, t.ss, t.n, ptr(s.t), s.ld, s.ss, s.n, s.S, t.C, t.S, ptr(out.t), out.ld,
-                              out.ss, ptr(ws), ptr(dbg), stream_ptr()))
+                              out.ss, ptr(ws), ws.numel(), ptr(dbg), stream_ptr()))
     if debug:
         d = dict(lo=dbg[..., 0], hi=dbg[..., 1], hist_t=dbg[..., 2:2 + BINS], hist_s=dbg[..., 2 + BINS:2 + 2 * BINS],
                  bin_edges=dbg[..., 2 + 2 * BINS:2 + 3 * BINS], remapped=dbg[..., 2 + 3 * BINS:])
@@ -116,7 +116,7 @@ def sort_columns(x, want_keys=True, want_idx=True):
     ok = torch.empty((S, C, n), dtype=torch.float32, device=x.device) if want_keys else None
     oi = torch.empty((S, C, n), dtype=torch.int32, device=x.device) if want_idx else None
     ws = workspace(lib.optex_sort_ws_bytes(n, C, S), x.device)
-    check(lib.optex_sort_columns(ptr(_f32c(x)), n, C * n, n, C, S, ptr(ok), ptr(oi), ptr(ws), stream_ptr()))
+    check(lib.optex_sort_columns(ptr(_f32c(x)), n, C * n, n, C, S, ptr(ok), ptr(oi), ptr(ws), ws.numel(), stream_ptr()))
     return ok, oi
 
 
@@ -127,7 +127,7 @@ def sort_match_seg(t: Seg, s: Seg, out: Seg = None):
         out = Seg.of(torch.empty((t.S, t.C, t.n), dtype=torch.float32, device=t.t.device))
     ws = workspace(lib.optex_sort_match_ws_bytes(t.n, s.n, t.C, t.S, s.S), t.t.device)
     check(lib.optex_sort_match(ptr(t.t), t.ld, t.ss, t.n, ptr(s.t), s.ld, s.ss, s.n, s.S, t.C, t.S, ptr(out.t), out.ld,
-                               out.ss, ptr(ws), stream_ptr()))
+                               out.ss, ptr(ws), ws.numel(), stream_ptr()))
     return out.t
 
 
@@ -139,7 +139,7 @@ def linear_stats(x: Seg, pool, eps=1.0):
     cov = torch.empty((x.C, x.C) if pool else (x.S, x.C, x.C), dtype=torch.float32, device=dev)
     ws = workspace(lib.optex_linear_stats_ws_bytes(x.n, x.C, x.S), dev)
     check(lib.optex_linear_stats(ptr(x.t), x.ld, x.ss, x.n, x.C, x.S, int(bool(pool)), ctypes.c_float(eps), ptr(mu),
-                                 ptr(cov), ptr(ws), stream_ptr()))
+                                 ptr(cov), ptr(ws), ws.numel(), stream_ptr()))
     return mu, cov
 
 
@@ -158,7 +158,7 @@ def rotations_from_normals(normals, N, count, device, want64=False):
     Rt32 = torch.empty_like(R32)
     R64 = torch.empty((count, N, N), dtype=torch.float64, device=device) if want64 else None
     ws = workspace(lib.optex_rotation_ws_bytes(N, count), device)
-    check(lib.optex_rotations_from_normals(ptr(nd), N, count, ptr(R64), ptr(R32), ptr(Rt32), ptr(ws), stream_ptr()))
+    check(lib.optex_rotations_from_normals(ptr(nd), N, count, ptr(R64), ptr(R32), ptr(Rt32), ptr(ws), ws.numel(), stream_ptr()))
     return (R32, Rt32, R64) if want64 else (R32, Rt32)
 
 
@@ -178,7 +178,7 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
     fuse = int(bool(fuse_rotations) and content is None)
     ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse), x.device)
     check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), iters,
-                            ptr(content), ctypes.c_float(strength), fuse, ptr(ws), stream_ptr()))
+                            ptr(content), ctypes.c_float(strength), fuse, ptr(ws), ws.numel(), stream_ptr()))
     return x
 
 

@@ -2,8 +2,10 @@
 PyTorch-ROCm (MIOpen) by the north-star's scoping; only the interface is kept: Encoder(depth) maps NCHW images to
 features, Decoder(depth) maps features back.  Module order inside the nn.Sequential matches the reference so that its
 state_dicts (`models/vgg_normalised_conv{d}_1.pth`, `models/feature_invertor_conv{d}_1.pth`, keys "2.weight" ...) load
-unchanged from `models_dir`.  Without a models_dir (the GPU box has no assets) weights are seeded synthetic
-(variance-preserving init), which leaves shapes, FLOPs and therefore throughput identical."""
+unchanged from `models_dir` (the relu1_1..relu3_1 files ship in assets/models; the reference's relu4_1 / relu5_1 files
+are absent from its own repository, `.MISSING_LARGE_BLOBS`).  A missing file RAISES like the reference does
+(vgg.py:147,166); seeded synthetic weights (variance-preserving init: same shapes, FLOPs and therefore throughput) are
+an explicit opt-in: `models_dir=None`, or `allow_synthetic=True` for the depths whose files do not exist."""
 import os
 
 import torch
@@ -125,7 +127,7 @@ def run_fused(model: nn.Sequential, x):
 class _Codec(nn.Module):
     FILE = ""
 
-    def __init__(self, depth: int, layers, models_dir=None, seed=0):
+    def __init__(self, depth: int, layers, models_dir=None, seed=0, allow_synthetic=False):
         super().__init__()
         assert isinstance(depth, int) and 1 <= depth <= 5
         self.depth = depth
@@ -134,6 +136,11 @@ class _Codec(nn.Module):
         if path and os.path.exists(path):
             self.model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
             self.weights = "pretrained:" + path
+        elif path and not allow_synthetic:
+            raise FileNotFoundError(
+                f"{path} not found (the reference fails the same way, vgg.py:147,166).  Pass allow_synthetic=True "
+                "(CLI: --synthetic_weights) to run this depth with seeded random weights, or models_dir=None for an "
+                "all-synthetic codec")
         else:
             _synthetic_init(self.model, seed + depth)
             self.weights = "synthetic(seed=%d)" % (seed + depth)
@@ -142,8 +149,8 @@ class _Codec(nn.Module):
 class Encoder(_Codec):
     FILE = "vgg_normalised_conv{}_1.pth"
 
-    def __init__(self, depth: int, models_dir=None):
-        super().__init__(depth, encoder_layers(depth), models_dir, seed=100)
+    def __init__(self, depth: int, models_dir=None, allow_synthetic=False):
+        super().__init__(depth, encoder_layers(depth), models_dir, seed=100, allow_synthetic=allow_synthetic)
 
     def features(self, x):
         """NCHW image -> NCHW feature (channel-major per image: the layout every OT kernel wants)"""
@@ -158,8 +165,8 @@ class Encoder(_Codec):
 class Decoder(_Codec):
     FILE = "feature_invertor_conv{}_1.pth"
 
-    def __init__(self, depth: int, models_dir=None):
-        super().__init__(depth, decoder_layers(depth), models_dir, seed=200)
+    def __init__(self, depth: int, models_dir=None, allow_synthetic=False):
+        super().__init__(depth, decoder_layers(depth), models_dir, seed=200, allow_synthetic=allow_synthetic)
 
     def decode(self, feat_nchw):
         if feat_nchw.is_cuda and not torch.is_grad_enabled():

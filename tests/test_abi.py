@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/optex.h but not exported by liboptex_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes and header disagree"
-    assert lib.optex_abi_version() == 2
+    assert lib.optex_abi_version() == 3
 
 
 def test_size_helpers_need_no_gpu():
@@ -37,7 +37,7 @@ def test_argument_errors_are_reported_without_launching():
     lib = _lib.load()
     rc = lib.optex_gemm_tn(None, 0, 0, None, 0, 0, 0, None, 0, 0, 0, 4, 4, 16, 1, None, 0, None, 0, None, 0.0, None)
     assert rc == -1 and b"optex_gemm_tn" in lib.optex_last_error()
-    rc = lib.optex_rotations_from_normals(None, 1, 1, None, None, None, None, None)
+    rc = lib.optex_rotations_from_normals(None, 1, 1, None, None, None, None, 0, None)
     assert rc == -1
     # glue: pool and upsample are exclusive; NHWC on both sides needs C % 4 == 0 (both rejected before any launch)
     import ctypes
@@ -47,6 +47,34 @@ def test_argument_errors_are_reported_without_launching():
     assert b"optex_vgg_glue_layout" in lib.optex_last_error()
     assert lib.optex_vgg_glue_layout(ptr, None, ptr, 1, 3, 4, 4, 0, 0, 0, 0, 1, 1, None) != 0
     assert b"C % 4" in lib.optex_last_error()
+
+
+def test_undersized_scratch_is_refused_before_any_launch():
+    """ABI 3: every entry point that takes `ws` also takes `ws_bytes` and refuses a buffer smaller than its *_ws_bytes
+    helper asks for (ABI 2 trusted the pointer: an undersized buffer was silent device-memory corruption)."""
+    import ctypes
+    lib = _lib.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    C, S, n, ns = 8, 2, 64, 48
+    need = lib.optex_cdf_ws_bytes(C, S)
+    rc = lib.optex_cdf_match(p, n, C * n, n, p, ns, C * ns, ns, 1, C, S, p, n, C * n, p, need - 1, None, None)
+    assert rc == -1 and b"scratch buffer too small" in lib.optex_last_error() and b"optex_cdf_match" in lib.optex_last_error()
+    need = lib.optex_sort_match_ws_bytes(n, ns, C, S, 1)
+    assert lib.optex_sort_match(p, n, C * n, n, p, ns, C * ns, ns, 1, C, S, p, n, C * n, p, need - 1, None) == -1
+    assert b"optex_sort_match" in lib.optex_last_error()
+    assert lib.optex_sort_columns(p, n, C * n, n, C, S, p, p, p, lib.optex_sort_ws_bytes(n, C, S) - 1, None) == -1
+    assert lib.optex_linear_stats(p, n, C * n, n, C, S, 0, 1.0, p, p, p, lib.optex_linear_stats_ws_bytes(n, C, S) - 1, None) == -1
+    assert b"optex_linear_stats" in lib.optex_last_error()
+    assert lib.optex_rotations_from_normals(p, 4, 2, None, p, p, p, lib.optex_rotation_ws_bytes(4, 2) - 1, None) == -1
+    for mode in (0, 1):
+        need = lib.optex_ot_loop_ws_bytes(mode, n, ns, C, S, 1, 3, 0)
+        assert lib.optex_ot_loop(mode, p, n, S, p, ns, 1, C, p, p, 3, None, 0.0, 0, p, need - 1, None) == -1
+        assert b"optex_ot_loop" in lib.optex_last_error()
+    # the sort-mode loop scratch covers pastiche columns longer than one LDS (ADVICE r1: it was sized with nt = 0)
+    big = lib.optex_ot_loop_ws_bytes(1, 65536, 49152, 64, 1, 1, 4, 0)
+    fixed = 4 * 64 * (65536 + 49152)
+    assert big - fixed >= lib.optex_sort_match_ws_bytes(65536, 49152, 64, 1, 1)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -521,15 +521,22 @@ def test_optimal_transport_pooled_batch_and_blend_golden(dev, golden):
 
 @pytest.mark.parametrize("mode", ["cdf", "sort"])
 def test_optimal_transport_hip_equals_oracle_bit_exact(dev, golden, mode):
-    """same R32 on both sides -> the whole step (GEMM, match, GEMM) is bit-identical, including the discontinuous cdf map"""
+    """The reference-API call with the rotation drawn on the device from numpy's global stream: the rotation the device
+    Householder chain produced is read back (same seed, same stream), and with THAT fp32 matrix on both sides the whole
+    step (GEMM, match, GEMM) must equal the oracle bit for bit, including the discontinuous cdf map.  The device
+    rotation itself is within 1 ulp (fp32) of the reference's golden matrix."""
     import optimaltextures_amd as ot
+    from optimaltextures_amd import rotation
     g = golden("optimal_transport.npz")
-    R = g["R_cdf"]
+    C = g["pastiche"].shape[-1]
+    np.random.seed(42)
+    R32 = rotation.rotations(C, 1, dev)[0][0].cpu().numpy()
+    ref32 = g["R_cdf"].astype(np.float32)
+    assert np.abs(R32 - ref32).max() <= np.spacing(np.float32(1.0))  # the golden rotation of np.random.seed(42), <= 1 ulp at 1
     np.random.seed(42)
     out = ot.optimal_transport(cu(g["pastiche"], dev), cu(g["style"], dev), mode).cpu().numpy()
-    want = orc.optimal_transport(g["pastiche"], g["style"], mode, R)
-    if not biteq(out, want):  # the device Householder chain may flip an fp32 ulp of R: fall back to the explicit-R path
-        pytest.skip("rotation differs by an ulp; covered by test_ot_loop_vs_oracle_bit_exact")
+    want = orc.optimal_transport(g["pastiche"], g["style"], mode, R32)
+    assert biteq(out, want)
 
 
 @pytest.mark.parametrize("mode", ["cdf", "sort"])
