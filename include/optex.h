@@ -110,12 +110,35 @@ int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt,
  *   cov = hist @ hist.T / N + eps * I.   pool = 0: one covariance per segment (independent textures);
  *   pool = 1: the reference's batch semantics — means per segment, ONE covariance pooled over all segments.
  * mu is [n_seg, C]; cov is [n_seg, C, C] (pool = 0) or [C, C] (pool = 1), fp32.
- * The C x C factorizations of histmatch.py:24-42 stay on torch.linalg (rocSOLVER); the apply GEMM
- * `T @ hist_t + mu_s` is optex_gemm_tn with bsub/badd.
+ * The C x C factorizations of histmatch.py:24-42 are K5 below; the apply GEMM `T @ hist_t + mu_s` is optex_gemm_tn
+ * with bsub/badd.
  * ------------------------------------------------------------------------------------------------- */
 size_t optex_linear_stats_ws_bytes(long n, int C, int n_seg);
 int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool, float eps,
                        float* mu, float* cov, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K5  the C x C algebra of the linear modes, histmatch.py:24-42, batched over independent segments on the device
+ * (csrc/linalg.hip) — replaces torch.linalg.cholesky / torch.inverse / torch.linalg.eigh of the reference.
+ *   optex_chol_inv:  A = L L^T (histmatch.py:25-26) and L^-1 (the `torch.inverse(chol_t)` of :27) in one pass.
+ *     U [batch, ld, ld] = L^T (upper), Linv [batch, ld, ld] = L^-1 (lower), ld = optex_chol_ld(C) = C rounded up to 32
+ *     (zero outside the triangle, identity in the padding).  C <= 512.
+ *   optex_spd_sqrt:  Y = A^1/2, Z = A^-1/2 of symmetric positive definite matrices — the `eve @ sqrt(diag(eva)) @ eve.T`
+ *     of histmatch.py:30-31,33,37,40 and its inverse, by the coupled Newton-Schulz iteration (GEMMs only; the spectrum
+ *     is bounded below by eps = 1).  Y, Z [batch, C, C] contiguous, either may be NULL.
+ *   optex_transfer_operator:  Tt[s] = T_s^T with  matched = T @ hist_t  for mode 2 = chol (L_s L_t^-1), 3 = pca
+ *     (Q_s Q_t^-1), 4 = sym (Q_t^-1 (Q_t S_s Q_t)^1/2 Q_t^-1);  cov_t [n_seg, C, C], cov_s [src_n_seg in {1, n_seg}, C, C]
+ *     (both with eps * I already added, as optex_linear_stats returns them), Tt [n_seg, C, C] — the `At` operand of
+ *     optex_gemm_tn for the apply step.
+ * ------------------------------------------------------------------------------------------------- */
+int optex_chol_ld(int C);
+int optex_chol_inv(const float* A, long a_seg_stride, int C, int batch, float* U, float* Linv, void* stream);
+size_t optex_spd_sqrt_ws_bytes(int C, int batch);
+int optex_spd_sqrt(const float* A, long a_seg_stride, int C, int batch, float* Y, float* Z, void* ws, size_t ws_bytes,
+                   void* stream);
+size_t optex_transfer_operator_ws_bytes(int mode, int C, int n_seg, int src_n_seg);
+int optex_transfer_operator(int mode, const float* cov_t, const float* cov_s, int C, int n_seg, int src_n_seg, float* Tt,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * R0  rotation generator, optex.py:142-149 -> scipy.stats.special_ortho_group.rvs (Householder chain, fp64).
@@ -130,15 +153,20 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
                                  void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * Fused hot loop, optex.py:112-117 for the modes that need no host-side factorization (cdf, sort):
+ * Fused hot loop, optex.py:112-117, every iteration of a (pass, layer) enqueued by one call:
  *   for it in range(iters):  x = ((x @ R_it) matched-to (style @ R_it)) @ R_it^T ; optional content blend
- * x is [n_seg, C, n] channel-major segments, updated in place; style is [src_n_seg, C, ns].
+ * x is [n_seg, C, n] channel-major segments (independent textures), updated in place; style is [src_n_seg, C, ns].
  * R32 / Rt32 are [iters, C, C] as produced by optex_rotations_from_normals.
- * mode: 0 = cdf, 1 = sort.
+ * mode: 0 = cdf, 1 = sort, 2 = chol, 3 = pca, 4 = sym (histmatch.py:5 `mode`; eps = 1 as every caller leaves it).
+ *   The linear modes (2-4) take the style's mean and covariance ONCE per call and rotate them as C x C matrices
+ *   (cov(S R) = R^T cov(S) R — the style-feature statistics the multi-GPU path broadcasts); the pastiche side is the
+ *   literal sequence: rotate, centre, covariance, transfer operator (K5), apply, rotate back.  C <= 512.
  * fuse_rotations = 0: the literal sequence above (three feature-map GEMMs per iteration, like the reference).
- * fuse_rotations = 1 (content must be NULL): `(m @ R_i^T) @ R_{i+1}` is evaluated as `m @ (R_i^T R_{i+1})` — the same
- *   product re-associated, one feature-map GEMM per iteration instead of two; agrees with the literal loop to fp32
- *   round-off per step.  An optional fast path, never the default.
+ * fuse_rotations = 1, optional fast paths, never the default, results agree to fp32 round-off per step:
+ *   cdf / sort (content must be NULL): `(m @ R_i^T) @ R_{i+1}` is evaluated as `m @ (R_i^T R_{i+1})` — one feature-map
+ *     GEMM per iteration instead of two;
+ *   linear modes: the whole step as ONE affine map in un-rotated space, x' = M (x - mu_x) + mu_s with M = R T R^T and
+ *     cov(x R) = R^T cov(x) R: one covariance + one feature-map GEMM per iteration instead of three.
  * ------------------------------------------------------------------------------------------------- */
 size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters,
                               int fuse_rotations);

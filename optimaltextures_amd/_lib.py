@@ -30,6 +30,12 @@ SIGNATURES = {
     "optex_sort_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _P]),
     "optex_linear_stats_ws_bytes": (_SZ, [_L, _I, _I]),
     "optex_linear_stats": (_I, [_P, _L, _L, _L, _I, _I, _I, _F, _P, _P, _P, _SZ, _P]),
+    "optex_chol_ld": (_I, [_I]),
+    "optex_chol_inv": (_I, [_P, _L, _I, _I, _P, _P, _P]),
+    "optex_spd_sqrt_ws_bytes": (_SZ, [_I, _I]),
+    "optex_spd_sqrt": (_I, [_P, _L, _I, _I, _P, _P, _P, _SZ, _P]),
+    "optex_transfer_operator_ws_bytes": (_SZ, [_I, _I, _I, _I]),
+    "optex_transfer_operator": (_I, [_I, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "optex_rotation_normals": (_L, [_I]),
     "optex_rotation_ws_bytes": (_SZ, [_I, _I]),
     "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),

@@ -183,6 +183,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     const float* __restrict__ Cp = a.content ? a.content + (size_t)seg * a.o_ss : nullptr;
     const float* __restrict__ badd = a.badd ? a.badd + (size_t)seg * a.badd_ss : nullptr;
     const float strength = a.strength;
+    const bool epi = !OPM && a.epi;
+    const float alpha = epi ? (a.alpha_seg ? a.alpha * a.alpha_seg[seg] : a.alpha) : 1.f;
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
 #pragma unroll
@@ -196,6 +198,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
                     if (m < a.M) {
                         float v = acc[tm][tn][r];
+                        if (epi) {
+                            v = v * alpha;
+                            if ((long)m == nn) v = v + a.diag;
+                        }
                         if (badd) v = v + badd[m];
                         const size_t off = (size_t)m * a.ldo + nn;
                         if (Cp) {
@@ -361,7 +367,7 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
         set_error("optex_gemm_tn: bad grid (%lld tiles)", total);
         return OPTEX_E_ARG;
     }
-    ProfScope prof(KC_GEMM, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
+    ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                    4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
     if (vec)
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WGM, WGN, BPM, OPM, true>), dim3((unsigned)total), dim3(NT), 0, st, a);
@@ -381,12 +387,12 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
-        if (!BPM && !OPM && vec && gemm_mfma16_env() && !a.bsub && !a.badd && !a.content && a.n % 128 == 0 && a.M % 4 == 0 &&
+        if (!BPM && !OPM && vec && gemm_mfma16_env() && !a.bsub && !a.badd && !a.content && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 &&
             a.M > 128 && huge >= 2LL * n_cu) {
             a.tiles_m = (a.M + 255) / 256;
             a.tiles_n = (int)(a.n / 128);
             const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
-            ProfScope prof(KC_GEMM, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
+            ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                            4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
             hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2>), dim3((unsigned)total), dim3(512), 0, st, a);
             return check_launch("gemm16_cm_kernel");
@@ -400,11 +406,23 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
 
 int device_cu_count();
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int gemm_tn_launch(GemmArgs& a, int b_layout, int o_layout, hipStream_t st) {
+    const bool bpm = b_layout == OPTEX_PIXEL_MAJOR, opm = o_layout == OPTEX_PIXEL_MAJOR;
+    // float4 paths need 16-byte aligned rows on every operand that is accessed with vectors
+    bool vec = aligned16(a.At) && a.lda % 4 == 0 && a.at_ss % 4 == 0 && aligned16(a.B) && a.ldb % 4 == 0 && a.b_ss % 4 == 0;
+    if (opm) vec = vec && aligned16(a.O) && a.ldo % 4 == 0 && a.o_ss % 4 == 0;
+    const int n_cu = device_cu_count();
+    if (!bpm && !opm) return launch_layout<false, false>(a, vec, n_cu, st);
+    if (bpm && !opm) return launch_layout<true, false>(a, vec, n_cu, st);
+    if (!bpm && opm) return launch_layout<false, true>(a, vec, n_cu, st);
+    return launch_layout<true, true>(a, vec, n_cu, st);
+}
+
 }  // namespace optex
 
 using namespace optex;
-
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int optex_gemm_tn(const float* At, long lda, long at_seg_stride, const float* B, long ldb,
                              long b_seg_stride, int b_layout, float* OUT, long ldo, long o_seg_stride, int o_layout,
@@ -429,15 +447,6 @@ extern "C" int optex_gemm_tn(const float* At, long lda, long at_seg_stride, cons
     a.bsub = bsub; a.bsub_ss = bsub_seg_stride;
     a.badd = badd; a.badd_ss = badd_seg_stride;
     a.content = content; a.strength = strength;
-    const bool bpm = b_layout == OPTEX_PIXEL_MAJOR, opm = o_layout == OPTEX_PIXEL_MAJOR;
-    // float4 paths need 16-byte aligned rows on every operand that is accessed with vectors
-    bool vec = aligned16(At) && lda % 4 == 0 && at_seg_stride % 4 == 0 && aligned16(B) && ldb % 4 == 0 &&
-               b_seg_stride % 4 == 0;
-    if (opm) vec = vec && aligned16(OUT) && ldo % 4 == 0 && o_seg_stride % 4 == 0;
-    hipStream_t st = as_stream(stream);
-    const int n_cu = device_cu_count();
-    if (!bpm && !opm) return launch_layout<false, false>(a, vec, n_cu, st);
-    if (bpm && !opm) return launch_layout<true, false>(a, vec, n_cu, st);
-    if (!bpm && opm) return launch_layout<false, true>(a, vec, n_cu, st);
-    return launch_layout<true, true>(a, vec, n_cu, st);
+    a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.prof_cls = KC_GEMM;
+    return gemm_tn_launch(a, b_layout, o_layout, as_stream(stream));
 }

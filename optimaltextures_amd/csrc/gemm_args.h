@@ -15,6 +15,13 @@ struct GemmArgs {
     const float* badd; long badd_ss;
     const float* content; float strength;
     int tiles_m, tiles_n;
+    // optional scaling epilogue of the small C x C products of the linear modes (linalg.hip), channel-major output only:
+    //   OUT = alpha * alpha_seg[seg] * acc + diag * (m == i)        (epi = 0: untouched, the hot-loop arithmetic)
+    int epi; float alpha; const float* alpha_seg; float diag;
+    int prof_cls;  // KC_GEMM for the feature-map GEMMs, KC_SMALL_GEMM for the C x C products of linalg.hip
 };
+
+// internal launcher behind optex_gemm_tn (gemm.hip): `a` fully filled except tiles_*; layouts are OPTEX_*_MAJOR
+int gemm_tn_launch(GemmArgs& a, int b_layout, int o_layout, hipStream_t st);
 
 }  // namespace optex

@@ -1,0 +1,353 @@
+// linalg.hip — the C x C algebra of the linear modes (histmatch.py:24-42) on the GPU, batched over independent
+// segments, so that the hot loop of `chol` / `pca` / `sym` (the reference's default is chol, optex.py:229) runs without a
+// host-side factorization between its kernels:
+//
+//   chol  T = L_s L_t^-1        chol_inv_kernel: one workgroup per matrix, left-looking blocked Cholesky that carries
+//                               the rows of L^-T along as extra right-hand sides, so L^T (= U) and L^-1 come out of one
+//                               pass; T^T = (L_t^-1)^T U_s is one batched C x C GEMM on the MFMA kernel of gemm.hip.
+//   pca   T = S_s^1/2 S_t^-1/2  coupled Newton-Schulz iteration  Y <- Y W, Z <- W Z, W = (3 I - Z Y) / 2  from
+//   sym   T = S_t^-1/2 (S_t^1/2 S_s S_t^1/2)^1/2 S_t^-1/2        Y0 = A / |A|_F, Z0 = I:  Y -> (A/|A|_F)^1/2, Z -> its inverse.
+//                               Only GEMMs (MFMA-shaped work, batched over all segments) instead of a batched symmetric
+//                               eigensolver: the reference's Q = V sqrt(L) V^T (histmatch.py:30-31) IS the principal
+//                               square root, and eps = 1 bounds the spectrum below by 1, so |A|_F / lambda_min stays in
+//                               the hundreds for VGG features and the iteration reaches fp32 round-off in <= 12 steps.
+//
+// Everything is fp32 like the reference's LAPACK calls; agreement with the reference is by tolerance (1e-4 per step,
+// SURVEY 8c), not bit-exact — summation orders differ.
+#include <cstdlib>
+
+#include "gemm_args.h"
+
+namespace optex {
+
+// ------------------------------------------------------------------------------------------------ small batched products
+// OUT[b] = alpha * alpha_seg[b] * (At[b]^T @ B[b]) + diag * I   for `batch` C x C matrices (strides in elements, 0 = shared)
+int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, long b_ss, float* O, long ldo, long o_ss, int C,
+               int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st) {
+    GemmArgs a;
+    a.At = At; a.lda = lda; a.at_ss = at_ss;
+    a.B = B; a.ldb = ldb; a.b_ss = b_ss;
+    a.O = O; a.ldo = ldo; a.o_ss = o_ss;
+    a.M = C; a.K = C; a.n = C; a.n_seg = batch;
+    a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
+    a.epi = epi ? 1 : 0; a.alpha = alpha; a.alpha_seg = alpha_seg; a.diag = diag;
+    a.prof_cls = KC_SMALL_GEMM;
+    return gemm_tn_launch(a, OPTEX_CHANNEL_MAJOR, OPTEX_CHANNEL_MAJOR, st);
+}
+
+// out[b][m] = sum_k R[b / per][k][m] * mu[(b % per)][k]   — the rotated style mean  mu_s @ R  (optex.py:171 + histmatch.py:20)
+__global__ void rot_mean_kernel(const float* __restrict__ R, const float* __restrict__ mu, int C, int per, float* __restrict__ out) {
+    const int b = blockIdx.x, it = b / per, s = b % per;
+    const float* r = R + (size_t)it * C * C;
+    const float* m = mu + (size_t)s * C;
+    for (int j = threadIdx.x; j < C; j += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < C; k++) acc = __builtin_fmaf(r[(size_t)k * C + j], m[k], acc);
+        out[(size_t)b * C + j] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Cholesky + inverse
+constexpr int CH_NB = 32;  // panel width
+
+// One workgroup per matrix, blockDim = 2 * NP (NP = C rounded up to a multiple of 32, <= 512).
+//   threads [0, NP):   row r of L                     (Cholesky:  A = L L^T)
+//   threads [NP, 2NP): row i of W = L^-T, i.e. column i of L^-1   (the same recurrence with A := I)
+// Left-looking by panels of 32 columns: a row's 32 panel entries live in registers; the already finished columns are read
+// back from global memory (U = L^T and Linv are written row by row = contiguous over the thread index, and stay in L2).
+// Outputs, both [NP, NP] with leading dimension NP, zero outside their triangle, identity in the padding:
+//   U[k][r]    = L[r][k]      (upper triangular, = L^T)
+//   Linv[k][i] = (L^-1)[k][i] (lower triangular)
+__global__ __launch_bounds__(1024) void chol_inv_kernel(const float* __restrict__ A, long a_ss, int C, int NP,
+                                                         float* __restrict__ U, float* __restrict__ Linv) {
+    extern __shared__ __align__(16) float ch_smem[];
+    float* pan = ch_smem;                          // [j0][32]: U[k][j0 .. j0+31] for the finished columns k < j0
+    float* dg = ch_smem + (size_t)(NP - CH_NB) * CH_NB;  // [32][33]: the diagonal block of the current panel
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* Ab = A + (size_t)b * a_ss;
+    float* Ub = U + (size_t)b * NP * NP;
+    float* Wb = Linv + (size_t)b * NP * NP;
+    const bool roleL = tid < NP;
+    const int r = roleL ? tid : tid - NP;          // row of L, or row of W
+    const int wave_first = r & ~63, wave_last = wave_first + 63;
+
+    for (int j0 = 0; j0 < NP; j0 += CH_NB) {
+        // ---- stage the panel's rows of the finished columns
+        for (int idx = tid; idx < j0 * (CH_NB / 4); idx += blockDim.x) {
+            const int k = idx / (CH_NB / 4), c4 = (idx % (CH_NB / 4)) * 4;
+            *reinterpret_cast<float4*>(pan + k * CH_NB + c4) = *reinterpret_cast<const float4*>(Ub + (size_t)k * NP + j0 + c4);
+        }
+        __syncthreads();
+        // ---- phase A: acc[c] = A[r][j0 + c] - sum_{k < j0} row[k] * L[j0 + c][k]
+        float acc[CH_NB];
+        const bool wave_active = roleL ? (wave_last >= j0) : (wave_first < j0 + CH_NB);
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            const int col = j0 + c;
+            float v;
+            if (!roleL || r >= C || col >= C) v = (r == col) ? 1.f : 0.f;   // W rows and the identity padding
+            else v = Ab[(size_t)col * C + r];                                // A is symmetric: read row `col`, contiguous in r
+            acc[c] = v;
+        }
+        if (wave_active) {
+            const float* src = roleL ? Ub : Wb;
+            // W[i][k] = 0 for k < i: a wave of W rows starts at its first row
+            const int k_beg = roleL ? 0 : wave_first;
+#pragma unroll 4
+            for (int k = k_beg; k < j0; k++) {
+                const float v = src[(size_t)k * NP + r];
+                const float4* p = reinterpret_cast<const float4*>(pan + k * CH_NB);
+#pragma unroll
+                for (int q = 0; q < CH_NB / 4; q++) {
+                    const float4 l = p[q];
+                    acc[4 * q + 0] = __builtin_fmaf(-v, l.x, acc[4 * q + 0]);
+                    acc[4 * q + 1] = __builtin_fmaf(-v, l.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = __builtin_fmaf(-v, l.z, acc[4 * q + 2]);
+                    acc[4 * q + 3] = __builtin_fmaf(-v, l.w, acc[4 * q + 3]);
+                }
+            }
+        }
+        // ---- phase B: the panel itself, column by column (the pivot row publishes its entries through dg)
+        float x[CH_NB];
+        const int rb = r - j0;  // position inside the diagonal block (L role only)
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            float t = acc[c];
+#pragma unroll
+            for (int k = 0; k < c; k++) t = __builtin_fmaf(-x[k], dg[c * (CH_NB + 1) + k], t);
+            const bool pivot = roleL && rb == c;
+            if (pivot) dg[c * (CH_NB + 1) + c] = sqrtf(t);
+            __syncthreads();
+            const float d = dg[c * (CH_NB + 1) + c];
+            x[c] = pivot ? d : __fdiv_rn(t, d);
+            if (roleL && rb > c && rb < CH_NB) dg[rb * (CH_NB + 1) + c] = x[c];
+            __syncthreads();
+        }
+        // ---- write the panel: U rows j0..j0+31 (entries r >= row), Linv rows j0..j0+31 (entries i <= row)
+        float* dst = roleL ? Ub : Wb;
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            const int row = j0 + c;
+            const bool keep = roleL ? (r >= row) : (r <= row);
+            dst[(size_t)row * NP + r] = keep ? x[c] : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+static size_t chol_lds_bytes(int NP) { return ((size_t)(NP - CH_NB) * CH_NB + CH_NB * (CH_NB + 1)) * sizeof(float); }
+
+int chol_np(int C) { return (C + CH_NB - 1) / CH_NB * CH_NB; }
+
+// A [batch] (C x C, stride a_ss) -> U, Linv [batch, NP, NP]
+int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st) {
+    const int NP = chol_np(C);
+    if (NP > 512) {
+        set_error("linear modes: C = %d > 512 channels is not supported by the batched Cholesky", C);
+        return OPTEX_E_UNSUPPORTED;
+    }
+    const size_t lds = chol_lds_bytes(NP);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chol_inv_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds_bytes(512));
+        if (e != hipSuccess) {
+            set_error("chol_inv_kernel: cannot reserve LDS: %s", hipGetErrorString(e));
+            return OPTEX_E_LAUNCH;
+        }
+        attr_done[dev & 63] = true;
+    }
+    // 2/3 C^3 flop for the factor + inverse; reads A, writes two triangles
+    ProfScope prof(KC_CHOL, st, (2.0 / 3.0) * (double)C * C * C * batch, 12.0 * (double)C * C * batch);
+    hipLaunchKernelGGL(chol_inv_kernel, dim3(batch), dim3(2 * NP), lds, st, A, a_ss, C, NP, U, Linv);
+    return check_launch("chol_inv_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------ Newton-Schulz square roots
+// Y0 = A / |A|_F, Z0 = I;  rs = sqrt(|A|_F), irs = 1 / rs  (the scale comes back in the last iteration's epilogue)
+__global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ A, long a_ss, int C, float* __restrict__ Y,
+                                                      float* __restrict__ Z, float* __restrict__ rs, float* __restrict__ irs) {
+    const int b = blockIdx.x;
+    const float* Ab = A + (size_t)b * a_ss;
+    const size_t cc = (size_t)C * C;
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < cc; i += blockDim.x) {
+        const double v = (double)Ab[i];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    __shared__ double sh[4];
+    __shared__ float fro_s;
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float fro = (float)sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        fro_s = fro;
+        const float r = sqrtf(fro);
+        rs[b] = r;
+        irs[b] = __fdiv_rn(1.f, r);
+    }
+    __syncthreads();
+    const float fro = fro_s;
+    float* Yb = Y + (size_t)b * cc;
+    float* Zb = Z + (size_t)b * cc;
+    for (size_t i = threadIdx.x; i < cc; i += blockDim.x) {
+        Yb[i] = __fdiv_rn(Ab[i], fro);
+        Zb[i] = (i / C == i % C) ? 1.f : 0.f;
+    }
+}
+
+int ns_iterations() {
+    static const int v = [] {
+        const char* e = getenv("OPTEX_NS_ITERS");
+        const int k = e ? atoi(e) : 16;
+        return k < 2 ? 2 : (k > 64 ? 64 : k);
+    }();
+    return v;
+}
+
+// Principal square root and inverse square root of `batch` symmetric positive definite C x C matrices.
+// buf: 6 * batch * C * C floats (Y, Z, W and their ping-pong partners) + 2 * batch floats.  The results land in
+// *Yout / *Zout (pointers into buf).
+size_t ns_ws_floats(int C, int batch) { return (size_t)6 * batch * C * C + 2 * (size_t)batch + 64; }
+
+int ns_sqrt(const float* A, long a_ss, int C, int batch, float* buf, float** Yout, float** Zout, hipStream_t st) {
+    const size_t cc = (size_t)C * C, sz = cc * batch;
+    float* Y = buf;
+    float* Z = buf + sz;
+    float* W = buf + 2 * sz;
+    float* Y2 = buf + 3 * sz;
+    float* Z2 = buf + 4 * sz;
+    float* rs = buf + 6 * sz;
+    float* irs = rs + batch;
+    {
+        ProfScope prof(KC_NS_INIT, st, 0.0, 12.0 * (double)cc * batch);
+        hipLaunchKernelGGL(ns_init_kernel, dim3(batch), dim3(256), 0, st, A, a_ss, C, Y, Z, rs, irs);
+    }
+    int rc = check_launch("ns_init_kernel");
+    if (rc) return rc;
+    const int K = ns_iterations();
+    for (int k = 0; k < K; k++) {
+        const bool last = k == K - 1;
+        // W = 1.5 I - 0.5 Z Y      (all iterates are polynomials in A: symmetric and commuting, so At^T B == At B)
+        if ((rc = small_gemm(Z, C, cc, Y, C, cc, W, C, cc, C, batch, true, -0.5f, nullptr, 1.5f, st))) return rc;
+        if ((rc = small_gemm(Y, C, cc, W, C, cc, Y2, C, cc, C, batch, last, 1.f, last ? rs : nullptr, 0.f, st))) return rc;
+        if ((rc = small_gemm(W, C, cc, Z, C, cc, Z2, C, cc, C, batch, last, 1.f, last ? irs : nullptr, 0.f, st))) return rc;
+        float* t = Y; Y = Y2; Y2 = t;
+        t = Z; Z = Z2; Z2 = t;
+    }
+    *Yout = Y;
+    *Zout = Z;
+    return OPTEX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ one transfer operator
+static int dcopy(float* dst, const float* src, size_t count, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        set_error("linalg: device copy failed: %s", hipGetErrorString(e));
+        return OPTEX_E_LAUNCH;
+    }
+    return OPTEX_OK;
+}
+
+struct TransferWs {
+    float *Us, *Ls, *Ut, *Lt;      // chol
+    float *ns_buf, *Ys, *Yt, *Zt, *G1, *G;  // pca / sym
+    size_t bytes;
+    TransferWs(void* ws, int mode, int C, int n_seg, int Ss) {
+        char* base = static_cast<char*>(ws);
+        size_t off = 0;
+        auto take = [&](size_t floats) {
+            float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+            off += align_up(floats * sizeof(float), 256);
+            return p;
+        };
+        const size_t cc = (size_t)C * C, pp = (size_t)chol_np(C) * chol_np(C);
+        Us = Ls = Ut = Lt = ns_buf = Ys = Yt = Zt = G1 = G = nullptr;
+        if (mode == 2) {
+            Us = take(Ss * pp); Ls = take(Ss * pp); Ut = take(n_seg * pp); Lt = take(n_seg * pp);
+        } else {
+            ns_buf = take(ns_ws_floats(C, n_seg > Ss ? n_seg : Ss));
+            Ys = take(Ss * cc); Yt = take(n_seg * cc); Zt = take(n_seg * cc); G1 = take(n_seg * cc); G = take(n_seg * cc);
+        }
+        bytes = off;
+    }
+};
+
+}  // namespace optex
+
+using namespace optex;
+
+extern "C" int optex_chol_ld(int C) { return chol_np(C); }
+
+extern "C" int optex_chol_inv(const float* A, long a_seg_stride, int C, int batch, float* U, float* Linv, void* stream) {
+    if (!A || !U || !Linv || C < 1 || batch < 1 || a_seg_stride < 0) {
+        set_error("optex_chol_inv: bad argument (C=%d batch=%d)", C, batch);
+        return OPTEX_E_ARG;
+    }
+    return launch_chol_inv(A, a_seg_stride, C, batch, U, Linv, as_stream(stream));
+}
+
+extern "C" size_t optex_spd_sqrt_ws_bytes(int C, int batch) { return ns_ws_floats(C, batch) * sizeof(float); }
+
+extern "C" int optex_spd_sqrt(const float* A, long a_seg_stride, int C, int batch, float* Y, float* Z, void* ws, size_t ws_bytes,
+                              void* stream) {
+    if (!A || C < 1 || batch < 1 || a_seg_stride < 0) {
+        set_error("optex_spd_sqrt: bad argument (C=%d batch=%d)", C, batch);
+        return OPTEX_E_ARG;
+    }
+    if (int rc = check_ws("optex_spd_sqrt", ws, ws_bytes, optex_spd_sqrt_ws_bytes(C, batch))) return rc;
+    hipStream_t st = as_stream(stream);
+    float *y, *z;
+    int rc = ns_sqrt(A, a_seg_stride, C, batch, static_cast<float*>(ws), &y, &z, st);
+    if (rc) return rc;
+    if (Y && (rc = dcopy(Y, y, (size_t)batch * C * C, st))) return rc;
+    if (Z && (rc = dcopy(Z, z, (size_t)batch * C * C, st))) return rc;
+    return OPTEX_OK;
+}
+
+extern "C" size_t optex_transfer_operator_ws_bytes(int mode, int C, int n_seg, int src_n_seg) {
+    return TransferWs(nullptr, mode, C, n_seg, src_n_seg).bytes;
+}
+
+extern "C" int optex_transfer_operator(int mode, const float* cov_t, const float* cov_s, int C, int n_seg, int src_n_seg,
+                                       float* Tt, void* ws, size_t ws_bytes, void* stream) {
+    if (!cov_t || !cov_s || !Tt || C < 1 || n_seg < 1 || (src_n_seg != 1 && src_n_seg != n_seg) || mode < 2 || mode > 4) {
+        set_error("optex_transfer_operator: bad argument (mode=%d C=%d n_seg=%d src_n_seg=%d; modes 2 = chol, 3 = pca, 4 = sym)",
+                  mode, C, n_seg, src_n_seg);
+        return OPTEX_E_ARG;
+    }
+    if (int rc = check_ws("optex_transfer_operator", ws, ws_bytes, optex_transfer_operator_ws_bytes(mode, C, n_seg, src_n_seg)))
+        return rc;
+    hipStream_t st = as_stream(stream);
+    TransferWs w(ws, mode, C, n_seg, src_n_seg);
+    const size_t cc = (size_t)C * C;
+    const int NP = chol_np(C), Ss = src_n_seg;
+    const size_t pp = (size_t)NP * NP;
+    int rc;
+    if (mode == 2) {  // histmatch.py:24-27
+        if ((rc = launch_chol_inv(cov_s, (long)cc, C, Ss, w.Us, w.Ls, st))) return rc;
+        if ((rc = launch_chol_inv(cov_t, (long)cc, C, n_seg, w.Ut, w.Lt, st))) return rc;
+        return small_gemm(w.Lt, NP, (long)pp, w.Us, NP, Ss > 1 ? (long)pp : 0, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+    }
+    float *Y, *Z;
+    if (mode == 3) {  // histmatch.py:29-34
+        if ((rc = ns_sqrt(cov_s, (long)cc, C, Ss, w.ns_buf, &Y, &Z, st))) return rc;
+        if ((rc = dcopy(w.Ys, Y, Ss * cc, st))) return rc;
+        if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+        return small_gemm(Z, C, (long)cc, w.Ys, C, Ss > 1 ? (long)cc : 0, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+    }
+    // histmatch.py:36-42
+    if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+    if ((rc = dcopy(w.Yt, Y, n_seg * cc, st))) return rc;
+    if ((rc = dcopy(w.Zt, Z, n_seg * cc, st))) return rc;
+    if ((rc = small_gemm(cov_s, C, Ss > 1 ? (long)cc : 0, w.Yt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+        return rc;
+    if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st))) return rc;
+    if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+    if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st))) return rc;
+    return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+}

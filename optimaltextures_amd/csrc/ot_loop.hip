@@ -1,51 +1,258 @@
-// ot_loop.hip — the reference's hot loop (optex.py:112-117) for the modes that need no host-side factorization:
+// ot_loop.hip — the reference's hot loop (optex.py:112-117), all iterations of a (pass, layer) enqueued back-to-back on
+// one stream from C++ (no Python, no host synchronisation between launches):
 //   for it in range(iters):  x = hist_match(x @ R, style @ R, mode) @ R.T ;  x += strength * (content - x)
-// enqueued back-to-back on one stream from C++ (no Python between launches).  Everything stays channel-major
-// ([segment][channel][pixel] = NCHW memory), so no kernel in the loop transposes anything.
-#include "optex_common.h"
+// Everything stays channel-major ([segment][channel][pixel] = NCHW memory), so no kernel in the loop transposes anything.
+//
+// modes 0 / 1 (cdf, sort): the style is rotated every iteration like the reference does (the matchers need its samples).
+// modes 2 / 3 / 4 (chol, pca, sym — histmatch.py:16-44): the matcher only needs the style's mean and covariance, and
+//   cov(S R) = R^T cov(S) R,  mean(S R) = mean(S) R   (the eps * I term is rotation-invariant),
+// so the style statistics are taken ONCE per call and rotated as C x C matrices for all iterations up front — exactly the
+// "style-feature statistics" the north star broadcasts between GPUs.  The pastiche side is literal: rotate, centre,
+// covariance, transfer operator, apply, rotate back — with the C x C factorizations on the device (linalg.hip).
+#include "gemm_args.h"
 
 using namespace optex;
 
+namespace optex {
+int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, long b_ss, float* O, long ldo, long o_ss, int C,
+               int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st);
+__global__ void rot_mean_kernel(const float* __restrict__ R, const float* __restrict__ mu, int C, int per, float* __restrict__ out);
+int chol_np(int C);
+int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st);
+size_t ns_ws_floats(int C, int batch);
+int ns_sqrt(const float* A, long a_ss, int C, int batch, float* buf, float** Yout, float** Zout, hipStream_t st);
+}  // namespace optex
+
 namespace {
-struct LoopWs {
-    float* y;    // rotated pastiche [n_seg, C, n]
-    float* ys;   // rotated style    [src_n_seg, C, ns]
-    float* y2;   // second rotated buffer (fused rotations only: the re-rotation cannot run in place)
-    float* P;    // [iters - 1, C, C] re-rotation matrices R_i^T R_{i+1} (fused rotations only)
-    void* mode_ws;
-    static size_t mode_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg) {
-        // the sort scratch depends on BOTH column lengths: pastiche columns longer than one LDS take the global radix
-        return mode == 0 ? optex_cdf_ws_bytes(C, n_seg) : optex_sort_match_ws_bytes(n, ns, C, n_seg, src_n_seg);
-    }
-    static size_t bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters, int fused) {
-        size_t b = align_up((size_t)n_seg * C * n * sizeof(float), 256) +
-                   align_up((size_t)src_n_seg * C * ns * sizeof(float), 256) + mode_bytes(mode, n, ns, C, n_seg, src_n_seg);
-        if (fused)
-            b += align_up((size_t)n_seg * C * n * sizeof(float), 256) +
-                 align_up((size_t)(iters > 1 ? iters - 1 : 1) * C * C * sizeof(float), 256);
-        return b;
-    }
-    LoopWs(void* ws, long n, long ns, int C, int n_seg, int src_n_seg, int iters, int fused) {
-        char* p = static_cast<char*>(ws);
-        y = reinterpret_cast<float*>(p);
-        p += align_up((size_t)n_seg * C * n * sizeof(float), 256);
-        ys = reinterpret_cast<float*>(p);
-        p += align_up((size_t)src_n_seg * C * ns * sizeof(float), 256);
-        y2 = P = nullptr;
-        if (fused) {
-            y2 = reinterpret_cast<float*>(p);
-            p += align_up((size_t)n_seg * C * n * sizeof(float), 256);
-            P = reinterpret_cast<float*>(p);
-            p += align_up((size_t)(iters > 1 ? iters - 1 : 1) * C * C * sizeof(float), 256);
-        }
-        mode_ws = p;
+
+enum { MODE_CDF = 0, MODE_SORT = 1, MODE_CHOL = 2, MODE_PCA = 3, MODE_SYM = 4 };
+constexpr float kEps = 1.0f;  // histmatch.py:5 `eps: float = 1`; no caller overrides it (optex.py:173,200-201)
+
+// bump allocator over the caller's scratch; with base == nullptr it only measures
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base(static_cast<char*>(b)) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += align_up(count * sizeof(T), 256);
+        return p;
     }
 };
+
+struct LoopWs {
+    // cdf / sort
+    float* y = nullptr;    // rotated pastiche [n_seg, C, n]
+    float* ys = nullptr;   // rotated style    [src_n_seg, C, ns]
+    float* y2 = nullptr;   // second rotated buffer (fused rotations: the re-rotation cannot run in place) / matched map (linear)
+    float* P = nullptr;    // [iters - 1, C, C] re-rotation matrices R_i^T R_{i+1} (fused rotations, cdf / sort)
+    void* mode_ws = nullptr;
+    size_t mode_ws_bytes = 0;
+    // linear modes
+    void* stats_ws = nullptr;
+    size_t stats_ws_bytes = 0;
+    float *mu_t = nullptr, *cov_t = nullptr, *mu_s = nullptr, *cov_s = nullptr;   // [n_seg, C], [n_seg, C, C], [Ss, C], [Ss, C, C]
+    float *tmp_s = nullptr, *cov_sr = nullptr, *mu_sr = nullptr;                  // per (iteration, style segment): [NS, C, C], [NS, C, C], [NS, C]
+    float* At = nullptr;                                                           // transfer operators, transposed: [n_seg, C, C]
+    float *Us = nullptr, *Ls = nullptr, *Ut = nullptr, *Lt = nullptr;              // chol: [NS | n_seg, NP, NP]
+    float *Ys = nullptr, *Yt = nullptr, *Zt = nullptr, *G1 = nullptr, *G = nullptr; // pca / sym
+    float* ns_buf = nullptr;
+    // fused (single-affine) linear path
+    float *M1 = nullptr, *Mt = nullptr, *mu_x = nullptr;
+
+    void layout(Bump& b, int mode, long n, long ns, int C, int n_seg, int Ss, int iters, int fused) {
+        const size_t xs = (size_t)n_seg * C * n, cc = (size_t)C * C;
+        if (mode == MODE_CDF || mode == MODE_SORT) {
+            y = b.take<float>(xs);
+            ys = b.take<float>((size_t)Ss * C * ns);
+            if (fused) {
+                y2 = b.take<float>(xs);
+                P = b.take<float>((size_t)(iters > 1 ? iters - 1 : 1) * cc);
+            }
+            // the sort scratch depends on BOTH column lengths: pastiche columns longer than one LDS take the global radix
+            mode_ws_bytes = mode == MODE_CDF ? optex_cdf_ws_bytes(C, n_seg) : optex_sort_match_ws_bytes(n, ns, C, n_seg, Ss);
+            mode_ws = b.take<char>(mode_ws_bytes);
+            return;
+        }
+        const size_t NS = (size_t)(iters > 0 ? iters : 1) * Ss;
+        const int NP = chol_np(C);
+        const size_t pp = (size_t)NP * NP;
+        const size_t nb = NS > (size_t)n_seg ? NS : (size_t)n_seg;
+        if (!fused) {
+            y = b.take<float>(xs);
+            y2 = b.take<float>(xs);
+        } else {
+            y2 = b.take<float>(xs);  // the affine map cannot run in place either
+            M1 = b.take<float>((size_t)n_seg * cc);
+            Mt = b.take<float>((size_t)n_seg * cc);
+            mu_x = b.take<float>((size_t)n_seg * C);
+        }
+        const int smax = n_seg > Ss ? n_seg : Ss;
+        const long nmax = n > ns ? n : ns;
+        stats_ws_bytes = optex_linear_stats_ws_bytes(nmax, C, smax);
+        stats_ws = b.take<char>(stats_ws_bytes);
+        mu_t = b.take<float>((size_t)n_seg * C);
+        cov_t = b.take<float>((size_t)n_seg * cc);
+        mu_s = b.take<float>((size_t)Ss * C);
+        cov_s = b.take<float>((size_t)Ss * cc);
+        tmp_s = b.take<float>(NS * cc);
+        cov_sr = b.take<float>(NS * cc);
+        mu_sr = b.take<float>(NS * C);
+        At = b.take<float>((size_t)n_seg * cc);
+        if (mode == MODE_CHOL) {
+            Us = b.take<float>(NS * pp);
+            Ls = b.take<float>(NS * pp);
+            Ut = b.take<float>((size_t)n_seg * pp);
+            Lt = b.take<float>((size_t)n_seg * pp);
+        } else {
+            ns_buf = b.take<float>(ns_ws_floats(C, (int)nb));
+            if (mode == MODE_PCA) Ys = b.take<float>(NS * cc);
+            Yt = b.take<float>((size_t)n_seg * cc);
+            Zt = b.take<float>((size_t)n_seg * cc);
+            G1 = b.take<float>((size_t)n_seg * cc);
+            G = b.take<float>((size_t)n_seg * cc);
+        }
+    }
+};
+
+int copy_async(float* dst, const float* src, size_t count, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        set_error("optex_ot_loop: device copy failed: %s", hipGetErrorString(e));
+        return OPTEX_E_LAUNCH;
+    }
+    return OPTEX_OK;
+}
+
+// feature-map GEMM with every option spelled out (the C ABI entry point with the loop's fixed layouts)
+int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, int n_seg, const float* bsub, const float* badd,
+          long badd_ss, const float* content, float strength, void* stream) {
+    const long xs = (long)C * n;
+    return optex_gemm_tn(At, C, at_ss, B, n, xs, OPTEX_CHANNEL_MAJOR, O, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, bsub, C,
+                         badd, badd_ss, content, strength, stream);
+}
+
+// Transfer operator of one iteration, transposed (At[k][m] = T[m][k], what the apply GEMM takes), for every pastiche
+// segment: cov_t [n_seg, C, C] (eps included) against the rotated style statistics of iteration `it`.
+int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg, int Ss, int it, hipStream_t st) {
+    const size_t cc = (size_t)C * C;
+    const int NP = chol_np(C);
+    const size_t pp = (size_t)NP * NP;
+    int rc;
+    if (mode == MODE_CHOL) {
+        // histmatch.py:24-27  T = L_s L_t^-1  ->  T^T = (L_t^-1)^T L_s^T = Linv_t^T @ U_s
+        if ((rc = launch_chol_inv(cov_t, (long)cc, C, n_seg, w.Ut, w.Lt, st))) return rc;
+        const float* Us = w.Us + (size_t)it * Ss * pp;
+        return small_gemm(w.Lt, NP, (long)pp, Us, NP, Ss > 1 ? (long)pp : 0, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr,
+                          0.f, st);
+    }
+    float *Y, *Z;
+    if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+    if (mode == MODE_PCA) {
+        // histmatch.py:29-34  T = Q_s Q_t^-1  ->  T^T = Q_t^-1 Q_s   (both symmetric)
+        const float* Ys = w.Ys + (size_t)it * Ss * cc;
+        return small_gemm(Z, C, (long)cc, Ys, C, Ss > 1 ? (long)cc : 0, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+    }
+    // histmatch.py:36-42  T = Q_t^-1 (Q_t S_s Q_t)^1/2 Q_t^-1   (symmetric: T^T = T)
+    if ((rc = copy_async(w.Yt, Y, (size_t)n_seg * cc, st))) return rc;
+    if ((rc = copy_async(w.Zt, Z, (size_t)n_seg * cc, st))) return rc;
+    const float* Cs = w.cov_sr + (size_t)it * Ss * cc;
+    if ((rc = small_gemm(Cs, C, Ss > 1 ? (long)cc : 0, w.Yt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+        return rc;                                                                    // S_s Q_t
+    if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+        return rc;                                                                    // Q_t S_s Q_t
+    if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;     // its square root
+    if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+        return rc;                                                                    // (.)^1/2 Q_t^-1
+    return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+}
+
+// style statistics once, rotated for every iteration:  cov_sr[it][s] = R_it^T cov(S_s) R_it + eps I,  mu_sr = R_it^T mu_s,
+// and the style-side factor of the mode (chol: U_s = L_s^T; pca: Q_s)
+int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int C, const float* R32, int iters, hipStream_t st,
+                  void* stream) {
+    const size_t cc = (size_t)C * C;
+    int rc;
+    if ((rc = optex_linear_stats(style, ns, (long)C * ns, ns, C, Ss, 0, 0.f, w.mu_s, w.cov_s, w.stats_ws, w.stats_ws_bytes, stream)))
+        return rc;
+    for (int s = 0; s < Ss; s++) {
+        // tmp[it][s] = cov_s @ R_it   (cov_s symmetric);   cov_sr[it][s] = R_it^T @ tmp + eps I
+        if ((rc = small_gemm(w.cov_s + (size_t)s * cc, C, 0, R32, C, (long)cc, w.tmp_s + (size_t)s * cc, C, (long)(cc * Ss), C, iters,
+                             false, 1.f, nullptr, 0.f, st)))
+            return rc;
+        if ((rc = small_gemm(R32, C, (long)cc, w.tmp_s + (size_t)s * cc, C, (long)(cc * Ss), w.cov_sr + (size_t)s * cc, C,
+                             (long)(cc * Ss), C, iters, true, 1.f, nullptr, kEps, st)))
+            return rc;
+    }
+    hipLaunchKernelGGL(rot_mean_kernel, dim3(iters * Ss), dim3(256), 0, st, R32, w.mu_s, C, Ss, w.mu_sr);
+    if ((rc = check_launch("rot_mean_kernel"))) return rc;
+    if (mode == MODE_CHOL) return launch_chol_inv(w.cov_sr, (long)cc, C, iters * Ss, w.Us, w.Ls, st);
+    if (mode == MODE_PCA) {
+        float *Y, *Z;
+        if ((rc = ns_sqrt(w.cov_sr, (long)cc, C, iters * Ss, w.ns_buf, &Y, &Z, st))) return rc;
+        return copy_async(w.Ys, Y, (size_t)iters * Ss * cc, st);
+    }
+    return OPTEX_OK;
+}
+
+int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int Ss, int C, const float* R32,
+                const float* Rt32, int iters, const float* content, float strength, int fused, LoopWs& w, void* stream) {
+    hipStream_t st = as_stream(stream);
+    const size_t cc = (size_t)C * C;
+    const long xs = (long)C * n;
+    int rc;
+    if ((rc = prepare_style(mode, w, style, ns, Ss, C, R32, iters, st, stream))) return rc;
+    float* cur = x;       // fused path: the affine map cannot run in place, x and y2 take turns
+    float* nxt = w.y2;
+    for (int it = 0; it < iters; it++) {
+        const float* R = R32 + (size_t)it * cc;
+        const float* Rt = Rt32 + (size_t)it * cc;
+        const float* mu_sr = w.mu_sr + (size_t)it * Ss * C;
+        if (!fused) {
+            // optex.py:170  rotated_pastiche = pastiche_feature @ rotation
+            if ((rc = fgemm(R, 0, x, w.y, C, n, n_seg, nullptr, nullptr, 0, nullptr, 0.f, stream))) return rc;
+            // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I
+            if ((rc = optex_linear_stats(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes, stream)))
+                return rc;
+            if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, Ss, it, st))) return rc;
+            // histmatch.py:27/34/42,44  matched = T @ hist_t + mu_s
+            if ((rc = fgemm(w.At, (long)cc, w.y, w.y2, C, n, n_seg, w.mu_t, mu_sr, Ss > 1 ? C : 0, nullptr, 0.f, stream))) return rc;
+            // optex.py:175 + 115-117  pastiche = matched @ rotation.T ; content blend
+            if ((rc = fgemm(Rt, 0, w.y2, x, C, n, n_seg, nullptr, nullptr, 0, content, strength, stream))) return rc;
+        } else {
+            // Single affine step in un-rotated space, the labelled fast path:
+            //   cov(x R) = R^T cov(x) R,   x' = M (x - mu_x) + mu_s   with   M = R T R^T
+            // one covariance and ONE feature-map GEMM per iteration instead of three.  small_gemm(L, B) = L^T @ B.
+            if ((rc = optex_linear_stats(cur, n, xs, n, C, n_seg, 0, 0.f, w.mu_x, w.cov_t, w.stats_ws, w.stats_ws_bytes, stream)))
+                return rc;
+            if ((rc = small_gemm(w.cov_t, C, (long)cc, R, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+                return rc;                                                                   // cov(x) R
+            if ((rc = small_gemm(R, C, 0, w.M1, C, (long)cc, w.Mt, C, (long)cc, C, n_seg, true, 1.f, nullptr, kEps, st)))
+                return rc;                                                                   // R^T cov(x) R + eps I
+            if ((rc = transfer_operators(mode, w, w.Mt, C, n_seg, Ss, it, st))) return rc;   // At = T^T
+            if ((rc = small_gemm(w.At, C, (long)cc, Rt, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+                return rc;                                                                   // (T^T)^T R^T = T R^T
+            if ((rc = small_gemm(w.M1, C, (long)cc, Rt, C, 0, w.Mt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+                return rc;                                                                   // (T R^T)^T R^T = R T^T R^T = M^T
+            // x' = M (x - mu_x) + mu_s  (R mu_sr = R R^T mu_s = the un-rotated style mean), content blend in the epilogue
+            if ((rc = fgemm(w.Mt, (long)cc, cur, nxt, C, n, n_seg, w.mu_x, w.mu_s, Ss > 1 ? C : 0, content, strength, stream)))
+                return rc;
+            float* t = cur; cur = nxt; nxt = t;
+        }
+    }
+    if (fused && cur != x) return copy_async(x, cur, (size_t)n_seg * xs, st);
+    return OPTEX_OK;
+}
+
 }  // namespace
 
 extern "C" size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters,
                                          int fuse_rotations) {
-    return LoopWs::bytes(mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations);
+    LoopWs w;
+    Bump b(nullptr);
+    w.layout(b, mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations);
+    return b.off;
 }
 
 extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
@@ -55,25 +262,36 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         set_error("optex_ot_loop: bad argument (n=%ld ns=%ld C=%d n_seg=%d iters=%d)", n, ns, C, n_seg, iters);
         return OPTEX_E_ARG;
     }
-    if (mode != 0 && mode != 1) {
-        set_error("optex_ot_loop: mode %d (0 = cdf, 1 = sort; the linear modes factorize on the host side)", mode);
+    if (mode < MODE_CDF || mode > MODE_SYM) {
+        set_error("optex_ot_loop: mode %d (0 = cdf, 1 = sort, 2 = chol, 3 = pca, 4 = sym)", mode);
         return OPTEX_E_ARG;
     }
     if (src_n_seg != 1 && src_n_seg != n_seg) {
         set_error("optex_ot_loop: style has %d segments, expected 1 or %d", src_n_seg, n_seg);
         return OPTEX_E_ARG;
     }
-    if (fuse_rotations && content) {
+    const bool linear = mode >= MODE_CHOL;
+    if (fuse_rotations && content && !linear) {
         set_error("optex_ot_loop: fuse_rotations needs the un-rotated pastiche between iterations for the content blend");
         return OPTEX_E_ARG;
+    }
+    if (linear && C > 512) {
+        set_error("optex_ot_loop: the linear modes support C <= 512 channels (got %d)", C);
+        return OPTEX_E_UNSUPPORTED;
     }
     if (int rc = check_ws("optex_ot_loop", ws, ws_bytes,
                           optex_ot_loop_ws_bytes(mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations)))
         return rc;
-    LoopWs w(ws, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations);
+    if (iters == 0) return OPTEX_OK;
+    LoopWs w;
+    Bump bump(ws);
+    w.layout(bump, mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations);
+    if (linear)
+        return linear_loop(mode, x, n, n_seg, style, ns, src_n_seg, C, R32, Rt32, iters, content, strength, fuse_rotations, w, stream);
+
     hipStream_t st = as_stream(stream);
     const long xs = (long)C * n, ss = (long)C * ns;
-    if (fuse_rotations && iters > 0) {
+    if (fuse_rotations) {
         // Re-association of optex.py:175 + :170 of the next iteration:  (m @ R_i^T) @ R_{i+1} == m @ (R_i^T R_{i+1}).
         // One feature-map GEMM per iteration instead of two; the C x C products P_i = R_i^T R_{i+1} cost nothing.
         // Same fp32 arithmetic contract (k-ordered fma chains), different association: results agree with the literal
@@ -94,7 +312,7 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
             if ((rc = optex_gemm_tn(R, C, 0, style, ns, ss, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C, C,
                                     ns, src_n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
                 return rc;
-            if (mode == 0)
+            if (mode == MODE_CDF)
                 rc = cdf_match_impl(cur, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, cur, n, xs, w.mode_ws, nullptr, st);
             else
                 rc = sort_match_impl(cur, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, cur, n, xs, w.mode_ws, st);
@@ -125,7 +343,7 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
                                 ns, src_n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
             return rc;
         // optex.py:173  hist_match(rotated_pastiche, rotated_style), in place
-        if (mode == 0)
+        if (mode == MODE_CDF)
             rc = cdf_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr, st);
         else
             rc = sort_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, st);

@@ -5,8 +5,8 @@
     around (vgg.py:153, histmatch.py:6-8,46) do not exist here, so no kernel in the loop transposes;
   * PCA project / unproject (optex.py:110,120) run on the same MFMA GEMM as the rotations;
   * all rotations of a (pass, layer) are generated in one batched device launch from one host draw of the numpy stream;
-  * cdf / sort iterations are enqueued by one C call (optex_ot_loop), the linear modes by a short Python loop around
-    torch.linalg's C x C factorizations;
+  * all iterations of a (pass, layer) are enqueued by one C call (optex_ot_loop) in every hist_mode — the linear modes'
+    C x C factorizations run on the device too (csrc/linalg.hip);
   * `independent=True` turns a batch into independent textures (one segment each, shared rotations): the reference's
     --batch pools all images into ONE distribution (histmatch.py:11,17-18), which is kept as the default.
 """
@@ -22,7 +22,7 @@ from .ops import Seg
 from .util import get_iters_and_sizes, get_size, layer_iters, resize, to_nchw, to_nhwc
 from .vgg import Decoder, Encoder
 
-LOOP_MODES = ("cdf", "sort")
+LOOP_MODES = ("cdf", "sort", "chol", "pca", "sym")
 
 
 # ------------------------------------------------------------------------------------------------ PCA (optex.py:180-190)
@@ -116,11 +116,12 @@ def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content:
         content = content.expand(s, c, n).contiguous()
     if pooled and s > 1:
         return _pooled_iterations(x, style, hist_mode, R32, Rt32, content, strength)
-    if hist_mode in LOOP_MODES:
+    if hist_mode not in LOOP_MODES:
+        raise ValueError(f"hist_mode must be one of chol|pca|sym|cdf|sort, got {hist_mode!r}")
+    if hist_mode not in LINEAR_MODES or c <= ops.LINEAR_MAX_C:
         return ops.ot_loop(hist_mode, x, style, R32, Rt32, content=content, strength=strength,
                            fuse_rotations=fuse_rotations)
-    if hist_mode not in LINEAR_MODES:
-        raise ValueError(f"hist_mode must be one of chol|pca|sym|cdf|sort, got {hist_mode!r}")
+    # linear modes wider than 512 channels: host loop around torch.linalg's factorizations
     ss = style.shape[0]
     y, ys, m = torch.empty_like(x), torch.empty_like(style), torch.empty_like(x)
     for it in range(iters):

@@ -4,8 +4,9 @@
     cdf_match(target, source, bins=256)              histmatch.py:49-69
     interp(x, xp, fp)                                histmatch.py:72-92
 
-Tensors are CUDA fp32.  All per-pixel work runs in the HIP kernels of liboptex_hip.so; only the C x C
-factorizations of the linear modes use torch.linalg (rocSOLVER), as SURVEY.md 8a/A5 scopes them.
+Tensors are CUDA fp32.  All work runs in the HIP kernels of liboptex_hip.so, the C x C factorizations of the linear modes
+included (csrc/linalg.hip: batched Cholesky + inverse, Newton-Schulz square roots); matrices wider than 512 channels
+fall back to torch.linalg (rocSOLVER).
 """
 import torch
 from torch import Tensor
@@ -32,6 +33,17 @@ def _spd_sqrt_pair(cov: Tensor):
 
 def transfer_operator(cov_t: Tensor, cov_s: Tensor, mode: str) -> Tensor:
     """T with matched = T @ hist_t (histmatch.py:24-42); cov_* are [..., C, C] (batched over independent segments)."""
+    if mode not in LINEAR_MODES:
+        raise ValueError(f"unknown linear mode {mode!r}")
+    c = cov_t.shape[-1]
+    if c <= ops.LINEAR_MAX_C:
+        ct, cs = cov_t.reshape(-1, c, c), cov_s.reshape(-1, c, c)
+        return ops.transfer_operator_t(ct, cs, mode).mT.reshape(cov_t.shape)
+    return _transfer_operator_torch(cov_t, cov_s, mode)
+
+
+def _transfer_operator_torch(cov_t: Tensor, cov_s: Tensor, mode: str) -> Tensor:
+    """the same operators on torch.linalg (rocSOLVER) for C > 512"""
     if mode == "chol":
         lt, ls = torch.linalg.cholesky(cov_t), torch.linalg.cholesky(cov_s)
         return torch.linalg.solve_triangular(lt, ls, upper=False, left=False)  # L_s @ L_t^-1
@@ -55,7 +67,10 @@ def linear_match_pooled(t_cm: Tensor, bt: int, s_cm: Tensor, bs: int, mode: str,
     mu_s, cov_s = ops.linear_stats(Seg.pooled(s_cm, bs), pool=True, eps=eps)
     if bs != bt and bs != 1 and bt != 1:
         raise RuntimeError(f"The size of tensor a ({bt}) must match the size of tensor b ({bs}) at non-singleton dimension 1")
-    Tt = transfer_operator(cov_t, cov_s, mode).mT.contiguous()  # At[k][m] = T[m][k]
+    if c <= ops.LINEAR_MAX_C:  # At[k][m] = T[m][k], straight from the device factorization
+        Tt = ops.transfer_operator_t(cov_t[None], cov_s[None], mode)[0]
+    else:
+        Tt = _transfer_operator_torch(cov_t, cov_s, mode).mT.contiguous()
     out = torch.empty_like(t_cm)
     late_bias = bt == 1 and bs > 1
     ops.gemm_tn(Tt, t_cm, out, c, c, n, bt, lda=c, ldb=nt, b_ss=n, ldo=nt, o_ss=n, bsub=mu_t, bsub_ss=c,

@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import CHANNEL_MAJOR, PIXEL_MAJOR, check, ptr, stream_ptr, workspace
 
 BINS = 256
-LOOP_MODES = {"cdf": 0, "sort": 1}
+LOOP_MODES = {"cdf": 0, "sort": 1, "chol": 2, "pca": 3, "sym": 4}  # optex_ot_loop / optex_transfer_operator mode codes
+LINEAR_MAX_C = 512
 
 
 def _f32c(t):
@@ -143,6 +144,45 @@ def linear_stats(x: Seg, pool, eps=1.0):
     return mu, cov
 
 
+def chol_inv(a):
+    """a [B, C, C] symmetric positive definite -> (U = L^T [B, C, C], Linv = L^-1 [B, C, C]) with a = L L^T
+    (histmatch.py:25-27: torch.linalg.cholesky + torch.inverse of the factor), one workgroup per matrix"""
+    lib = _lib.lib()
+    a = _f32c(a).contiguous()
+    b, c, _ = a.shape
+    ld = lib.optex_chol_ld(c)
+    u = torch.empty((b, ld, ld), dtype=torch.float32, device=a.device)
+    li = torch.empty_like(u)
+    check(lib.optex_chol_inv(ptr(a), c * c, c, b, ptr(u), ptr(li), stream_ptr()))
+    return u[:, :c, :c], li[:, :c, :c]
+
+
+def spd_sqrt(a):
+    """a [B, C, C] symmetric positive definite -> (a^1/2, a^-1/2): the reference's eve @ sqrt(diag(eva)) @ eve.T
+    (histmatch.py:30-31) and its inverse, by Newton-Schulz iterations on the MFMA GEMM"""
+    lib = _lib.lib()
+    a = _f32c(a).contiguous()
+    b, c, _ = a.shape
+    y, z = torch.empty_like(a), torch.empty_like(a)
+    ws = workspace(lib.optex_spd_sqrt_ws_bytes(c, b), a.device)
+    check(lib.optex_spd_sqrt(ptr(a), c * c, c, b, ptr(y), ptr(z), ptr(ws), ws.numel(), stream_ptr()))
+    return y, z
+
+
+def transfer_operator_t(cov_t, cov_s, mode):
+    """T^T per segment (the `At` operand of the apply GEMM): cov_t [S, C, C], cov_s [1 or S, C, C], eps * I included
+    (histmatch.py:24-42)"""
+    lib = _lib.lib()
+    cov_t, cov_s = _f32c(cov_t).contiguous(), _f32c(cov_s).contiguous()
+    s, c, _ = cov_t.shape
+    ss = cov_s.shape[0]
+    m = LOOP_MODES[mode]
+    out = torch.empty_like(cov_t)
+    ws = workspace(lib.optex_transfer_operator_ws_bytes(m, c, s, ss), cov_t.device)
+    check(lib.optex_transfer_operator(m, ptr(cov_t), ptr(cov_s), c, s, ss, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+    return out
+
+
 def rotation_normals(N):
     return int(_lib.load().optex_rotation_normals(int(N)))
 
@@ -163,9 +203,10 @@ def rotations_from_normals(normals, N, count, device, want64=False):
 
 
 def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False):
-    """optex.py:112-117 fused on device for mode in {"cdf", "sort"}; x [S, C, n] is updated IN PLACE.
-    fuse_rotations: evaluate (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (one GEMM per iteration instead of two; fp32
-    round-off differences only; needs content=None)."""
+    """optex.py:112-117, all iterations enqueued by one C call, for every hist_mode; x [S, C, n] (independent segments) is
+    updated IN PLACE.  fuse_rotations (labelled fast paths, fp32 round-off differences only): cdf / sort evaluate
+    (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (needs content=None); the linear modes run the whole step as one
+    affine map in un-rotated space."""
     lib = _lib.lib()
     S, C, n = x.shape
     Ss, Cs, ns = style.shape
@@ -175,7 +216,7 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
     if content is not None:
         assert content.shape == x.shape and content.is_contiguous()
     m = LOOP_MODES[mode]
-    fuse = int(bool(fuse_rotations) and content is None)
+    fuse = int(bool(fuse_rotations) and (content is None or m >= 2))
     ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse), x.device)
     check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), iters,
                             ptr(content), ctypes.c_float(strength), fuse, ptr(ws), ws.numel(), stream_ptr()))
