@@ -252,7 +252,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
 // OPTEX_GEMM_MFMA16=0 disables it.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+// EXTRA = true adds the operand centring (bsub), the output bias (badd) and the content blend of the general kernel, with
+// the same arithmetic in the same order (bit-identical to gemm_tn_kernel): the apply GEMM of the linear modes
+// (histmatch.py:27/34/42,44) and the blending inverse rotation of style transfer (optex.py:115-117, 175) take this path too.
+template <int BM, int BN, int BK, int WGM, int WGN, bool EXTRA>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
     const long n0 = (long)tn_idx * BN;
     const float* __restrict__ At = a.At + (size_t)seg * a.at_ss;
     const float* __restrict__ Bp = a.B + (size_t)seg * a.b_ss;
+    const float* __restrict__ bsub = (EXTRA && a.bsub) ? a.bsub + (size_t)seg * a.bsub_ss : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -288,7 +292,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
             const int k = idx / (BN / 4);
             const long nn = n0 + (idx % (BN / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + k < a.K) v = *reinterpret_cast<const float4*>(Bp + (size_t)(k0 + k) * a.ldb + nn);
+            if (k0 + k < a.K) {
+                v = *reinterpret_cast<const float4*>(Bp + (size_t)(k0 + k) * a.ldb + nn);
+                if (EXTRA && bsub) {
+                    const float s = bsub[k0 + k];
+                    v.x -= s; v.y -= s; v.z -= s; v.w -= s;
+                }
+            }
             rb[i] = v;
         }
     };
@@ -336,6 +346,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
     }
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
     float* __restrict__ Op = a.O + (size_t)seg * a.o_ss;
+    const float* __restrict__ Cp = (EXTRA && a.content) ? a.content + (size_t)seg * a.o_ss : nullptr;
+    const float* __restrict__ badd = (EXTRA && a.badd) ? a.badd + (size_t)seg * a.badd_ss : nullptr;
+    const float strength = a.strength;
 #pragma unroll
     for (int tm = 0; tm < TM; tm++)
 #pragma unroll
@@ -344,7 +357,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int m = m0 + wm * WM + tm * 16 + 4 * kq + r;
-                if (m < a.M) Op[(size_t)m * a.ldo + nn] = acc[tm][tn][r];
+                if (m < a.M) {
+                    float v = acc[tm][tn][r];
+                    const size_t off = (size_t)m * a.ldo + nn;
+                    if (EXTRA) {
+                        if (badd) v = v + badd[m];
+                        if (Cp) {
+                            const float d = Cp[off] - v;
+                            const float sd = strength * d;
+                            v = v + sd;
+                        }
+                    }
+                    Op[off] = v;
+                }
             }
         }
 }
@@ -387,14 +412,17 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
-        if (!BPM && !OPM && vec && gemm_mfma16_env() && !a.bsub && !a.badd && !a.content && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 &&
-            a.M > 128 && huge >= 2LL * n_cu) {
+        if (!BPM && !OPM && vec && gemm_mfma16_env() && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 && a.M > 128 &&
+            huge >= 2LL * n_cu) {
             a.tiles_m = (a.M + 255) / 256;
             a.tiles_n = (int)(a.n / 128);
             const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
             ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                            4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
-            hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2>), dim3((unsigned)total), dim3(512), 0, st, a);
+            if (a.bsub || a.badd || a.content)
+                hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2, true>), dim3((unsigned)total), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2, false>), dim3((unsigned)total), dim3(512), 0, st, a);
             return check_launch("gemm16_cm_kernel");
         }
         if (a.M > 128 && huge >= 2LL * n_cu) return launch_cfg<256, 128, 16, 4, 2, BPM, OPM>(a, vec, st);

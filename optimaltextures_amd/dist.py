@@ -1,9 +1,9 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL ("nccl" backend on ROCm) on xGMI.
 
 The hot path shards by independent textures: texture i is synthesised entirely on one rank, nothing is
-exchanged during iteration.  The only collective is a broadcast, once per (pass, layer), of the style-side data
-(PCA basis + style features) so that one rank encodes / SVD-fits the style and the others receive <= 12 MB over xGMI
-— latency-bound, far from the per-link bandwidth.  On CPU (tests) the same code runs over gloo."""
+exchanged during iteration.  The only collective is a broadcast, once per forward call, of the style side of every
+(pass, layer) — style features + PCA basis, packed into one buffer (<= 12 MB per layer at 512^2) — so that one rank
+encodes / SVD-fits the style and the others receive it over xGMI: latency-bound, far from the per-link bandwidth.  On CPU (tests) the same code runs over gloo."""
 import os
 from typing import List, Optional, Tuple
 
@@ -39,52 +39,98 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+def _padded(numel: int) -> int:
+    return (numel + 63) // 64 * 64
+
+
 class StyleSync:
-    """Callable hook for OptimalTexture.style_sync: rank `src` passes its list of tensors, everyone gets them back."""
+    """Hook for OptimalTexture.style_sync: rank `src` owns the style side of a forward call, everyone gets it back.
+
+    One exchange = TWO messages whatever the number of tensors: a fixed-size int64 header (tensor count, shapes, and any
+    integers that travel along, e.g. feature-map sizes) and ONE flat fp32 payload holding every tensor back to back.
+    The header is the only host synchronisation of the receiving ranks (the PCA rank k is data dependent, so shapes
+    cannot be known in advance); the payload broadcast is issued asynchronously — over RCCL it runs on the
+    communicator's own stream and the consumers' stream merely waits for it — and the received tensors are views into
+    the flat buffer."""
+
+    MAX_TENSORS, MAX_INTS = 160, 320
+    HEADER = 3 + MAX_TENSORS * (1 + MAX_DIMS) + MAX_INTS
 
     def __init__(self, device, src: int = 0, group=None):
         self.device, self.src, self.group = torch.device(device), src, group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.bytes_moved = 0
+        self.bytes_moved = 0    # payload + header bytes this rank sent or received
+        self.messages = 0       # broadcast calls issued
 
     @property
     def is_source(self) -> bool:
         return self.rank == self.src
 
-    def __call__(self, payload: Optional[List[torch.Tensor]]) -> List[torch.Tensor]:
+    def broadcast_packed(self, tensors: Optional[List[torch.Tensor]], ints: Optional[List[int]] = None):
+        """source: (list of fp32 tensors, list of ints) -> everyone: (list of tensors, list of ints)"""
         if self.world == 1:
-            return payload
-        # 1. shapes (count and dims differ per pass: the PCA rank k is data dependent)
-        meta = torch.zeros(1 + 8 * (1 + MAX_DIMS), dtype=torch.int64, device=self.device)
+            return list(tensors), list(ints or [])
+        header = torch.zeros(self.HEADER, dtype=torch.int64)
+        flat = None
         if self.is_source:
-            assert payload is not None and len(payload) <= 8
-            meta[0] = len(payload)
-            for i, t in enumerate(payload):
+            ints = list(ints or [])
+            assert tensors is not None and len(tensors) <= self.MAX_TENSORS and len(ints) <= self.MAX_INTS
+            header[0], header[1] = len(tensors), len(ints)
+            for i, t in enumerate(tensors):
                 assert t.dim() <= MAX_DIMS and t.dtype == torch.float32
-                meta[1 + i * (1 + MAX_DIMS)] = t.dim()
+                base = 3 + i * (1 + MAX_DIMS)
+                header[base] = t.dim()
                 for d, sz in enumerate(t.shape):
-                    meta[2 + i * (1 + MAX_DIMS) + d] = sz
-        dist.broadcast(meta, self.src, group=self.group)
-        m = meta.tolist()
-        out = []
-        for i in range(m[0]):
-            nd = m[1 + i * (1 + MAX_DIMS)]
-            shape = m[2 + i * (1 + MAX_DIMS):2 + i * (1 + MAX_DIMS) + nd]
-            if self.is_source:
-                t = payload[i].to(self.device).contiguous()
-            else:
-                t = torch.empty(shape, dtype=torch.float32, device=self.device)
-            if t.numel():
-                dist.broadcast(t, self.src, group=self.group)
-                self.bytes_moved += t.numel() * 4
-            out.append(t)
-        return out
+                    header[base + 1 + d] = sz
+            header[2] = sum(_padded(t.numel()) for t in tensors)
+            if ints:
+                header[3 + self.MAX_TENSORS * (1 + MAX_DIMS):3 + self.MAX_TENSORS * (1 + MAX_DIMS) + len(ints)] = torch.tensor(ints)
+            flat = torch.empty(int(header[2]), dtype=torch.float32, device=self.device)
+            off = 0
+            for t in tensors:  # every tensor starts on a 256-byte boundary: the kernels' 16-byte vector paths stay usable
+                flat[off:off + t.numel()].copy_(t.reshape(-1))
+                off += _padded(t.numel())
+        header = header.to(self.device)
+        dist.broadcast(header, self.src, group=self.group)
+        h = header.tolist()  # the one host synchronisation of a receiving rank
+        n_t, n_i, total = h[0], h[1], h[2]
+        if flat is None:
+            flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        work = dist.broadcast(flat, self.src, group=self.group, async_op=True) if total else None
+        self.messages += 2 if total else 1
+        self.bytes_moved += total * 4 + self.HEADER * 8
+        out, off = [], 0
+        for i in range(n_t):
+            base = 3 + i * (1 + MAX_DIMS)
+            shape = h[base + 1:base + 1 + h[base]]
+            numel = 1
+            for sz in shape:
+                numel *= sz
+            out.append(flat[off:off + numel].view(shape))
+            off += _padded(numel)
+        if work is not None:
+            work.wait()  # RCCL: the current stream waits for the communicator's stream, the host does not block
+        ibase = 3 + self.MAX_TENSORS * (1 + MAX_DIMS)
+        return out, h[ibase:ibase + n_i]
+
+    def __call__(self, payload: Optional[List[torch.Tensor]]) -> List[torch.Tensor]:
+        return self.broadcast_packed(payload)[0]
 
 
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+def all_gather_floats(value: float, device) -> List[float]:
+    """every rank's value, in rank order (bench.py reports per-rank step times so a scaling loss can be located)"""
+    if not dist.is_initialized():
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def all_reduce_max(value: float, device) -> float:

@@ -199,46 +199,76 @@ class OptimalTexture(torch.nn.Module):
             return styles
         return [resize(s, size=get_size(size, self.style_scale, s.shape[2], s.shape[3])) for s in styles]
 
-    def _style_side(self, style_tens: Optional[List[Tensor]]):
-        """per encoder: style features [n_styles, k, Hs*Ws] (channel-major), PCA basis, feature-map size.  With a
-        style_sync hook only its source rank encodes / fits; everyone receives the result (dist.StyleSync)."""
+    def _compute_style_side(self, style_tens: List[Tensor]):
+        """per encoder: style features [n_styles, k, Hs*Ws] (channel-major), PCA basis [C, k] (empty without PCA),
+        feature-map size — local work, no communication"""
         style_features, style_eigvs, style_hw = [], [], []
         for encoder in self.encoders:
-            payload, hw = None, None
-            if self.style_sync is None or self.style_sync.is_source:
-                sf = torch.cat([encoder.features(s) for s in style_tens])  # [n_styles, C, Hs, Ws]
-                hw = (int(sf.shape[2]), int(sf.shape[3]))
-                sf = sf.reshape(sf.shape[0], sf.shape[1], -1)
-                if self.use_pca:
-                    sf, eigvecs = fit_pca_cm(sf)
-                else:
-                    eigvecs = torch.empty((0, 0), device=sf.device)
-                payload = [sf.contiguous(), eigvecs, torch.tensor(list(hw), device=sf.device, dtype=torch.float32)]
-            if self.style_sync is not None:
-                payload = self.style_sync(payload)
-            sf, eigvecs, hw_t = payload
-            if hw is None:  # received: the size travels with the payload
-                hw = (int(hw_t[0].item()), int(hw_t[1].item()))
-            style_features.append(sf)
+            sf = torch.cat([encoder.features(s) for s in style_tens])  # [n_styles, C, Hs, Ws]
+            style_hw.append((int(sf.shape[2]), int(sf.shape[3])))
+            sf = sf.reshape(sf.shape[0], sf.shape[1], -1)
+            if self.use_pca:
+                sf, eigvecs = fit_pca_cm(sf)
+            else:
+                eigvecs = torch.empty((0, 0), device=sf.device)
+            style_features.append(sf.contiguous())
             style_eigvs.append(eigvecs)
-            style_hw.append(hw)
         return style_features, style_eigvs, style_hw
+
+    def _sync_style_sides(self, sides):
+        """sides: list of (resized, features, eigvecs, hw) known on the source rank (None elsewhere) -> the same list on
+        every rank.  ONE packed broadcast for all of them (dist.StyleSync.broadcast_packed): two messages and one host
+        synchronisation per call, whatever the number of passes and layers."""
+        if self.style_sync is None:
+            return sides
+        n_enc = len(self.encoders)
+        tensors, ints = None, None
+        if self.style_sync.is_source:
+            tensors, ints = [], [len(sides)]
+            for resized, sf, eig, hw in sides:
+                ints.append(int(resized))
+                for f, e, (h, w) in zip(sf, eig, hw):
+                    tensors += [f, e]
+                    ints += [h, w]
+        tensors, ints = self.style_sync.broadcast_packed(tensors, ints)
+        out, ti, ii = [], 0, 1
+        for _ in range(ints[0]):
+            resized = bool(ints[ii])
+            ii += 1
+            sf, eig, hw = [], [], []
+            for _ in range(n_enc):
+                sf.append(tensors[ti])
+                eig.append(tensors[ti + 1])
+                hw.append((int(ints[ii]), int(ints[ii + 1])))
+                ti += 2
+                ii += 2
+            out.append((resized, sf, eig, hw))
+        return out
+
+    def _style_side(self, style_tens: Optional[List[Tensor]]):
+        """the style side of ONE pass (the fallback when nothing was prefetched); with a style_sync hook only its source
+        rank encodes / fits, everyone receives the result"""
+        need = self.style_sync is None or self.style_sync.is_source
+        side = [(False,) + self._compute_style_side(style_tens)] if need else None
+        return self._sync_style_sides(side)[0][1:]
 
     def prefetch_style_sides(self, pastiche_hw, styles: List[Tensor], content: Optional[Tensor]):
         """The style side of EVERY pass, before the first one starts.  It depends on the pastiche only through its
-        size, which is known in advance (each pass leaves the pastiche at its content size).  With a style_sync hook this
-        puts all broadcasts — and the host synchronisations that learning the PCA shapes costs the receiving ranks — at
-        the start of a forward call instead of one per pass in the middle of the receivers' kernel queues."""
+        size, which is known in advance (each pass leaves the pastiche at its content size).  With a style_sync hook the
+        source rank encodes them all and ONE packed broadcast carries them: the receiving ranks pay a single host
+        synchronisation (the PCA shapes are data dependent) at the start of a forward call, before their kernel queue
+        fills, instead of one per (pass, layer) in the middle of it."""
         hw, sides = (int(pastiche_hw[0]), int(pastiche_hw[1])), []
+        need = self.style_sync is None or self.style_sync.is_source
         for p in range(self.passes):
             size = self.sizes[p]
             resized = self._needs_resize(hw, size)
-            need = self.style_sync is None or self.style_sync.is_source
-            sides.append((resized,) + self._style_side(self._style_tensors(styles, size, resized) if need else None))
+            if need:
+                sides.append((resized,) + self._compute_style_side(self._style_tensors(styles, size, resized)))
             if resized:
                 hw = (get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True) if content is not None
                       else (size, size))
-        return sides
+        return self._sync_style_sides(sides if need else None)
 
     def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int,
                       style_side=None):

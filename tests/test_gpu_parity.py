@@ -101,6 +101,30 @@ def test_gemm_bias_and_content_blend_bit_exact(dev):
         assert biteq(got[s], want)
 
 
+def test_gemm_hot_loop_tile_with_bias_and_blend_bit_exact(dev):
+    """the 16x16x4-MFMA hot-loop kernel (M = K = 256, whole pixel tiles, >= 2 tiles per CU) also carries the centring, the
+    bias and the content blend: per-segment operators as in the linear modes' apply step, bit-exact vs the oracle"""
+    from optimaltextures_amd import ops
+    rng = np.random.default_rng(6)
+    S, C, n = 4, 256, 16384
+    x = rng.standard_normal((S, C, n)).astype(np.float32)
+    At = (rng.standard_normal((S, C, C)) / 16).astype(np.float32)
+    bsub = rng.standard_normal((S, C)).astype(np.float32)
+    badd = rng.standard_normal((S, C)).astype(np.float32)
+    content = rng.standard_normal((S, C, n)).astype(np.float32)
+    out = torch.empty((S, C, n), dtype=torch.float32, device=dev)
+    ops.gemm_tn(cu(At, dev), cu(x, dev), out, C, C, n, S, lda=C, at_ss=C * C, ldb=n, b_ss=C * n, ldo=n, o_ss=C * n,
+                bsub=cu(bsub, dev), bsub_ss=C, badd=cu(badd, dev), badd_ss=C, content=cu(content, dev), strength=0.05)
+    got = out.cpu().numpy()
+    for s in (0, 3):
+        want = orc.content_blend(orc.gemm_tn(At[s], x[s], bsub[s], badd[s]), content[s], 0.05)
+        assert biteq(got[s], want)
+    out2 = torch.empty_like(out)  # blend only (the inverse rotation of style transfer)
+    ops.gemm_tn(cu(At[0], dev), cu(x, dev), out2, C, C, n, S, lda=C, ldb=n, b_ss=C * n, ldo=n, o_ss=C * n,
+                content=cu(content, dev), strength=0.0125)
+    assert biteq(out2.cpu().numpy()[2], orc.content_blend(orc.gemm_tn(At[0], x[2]), content[2], 0.0125))
+
+
 # ================================================================================================ K2a/K2b stages
 def test_minmax_and_histc_stage_known_answers(dev, golden):
     from optimaltextures_amd import ops
