@@ -44,22 +44,26 @@ def synthetic_style(device, seed=0):
     return (img + 0.05 * torch.randn(1, 3, 736, 512, generator=g)).clamp(0, 1).to(device)
 
 
-def make_texturizer(hist_mode, device, fuse_rotations=False):
-    return OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode=hist_mode, no_pca=True, layers=(LAYER,),
-                          independent=True, fuse_rotations=fuse_rotations).to(device).eval()
+def make_texturizer(hist_mode, device, fuse_rotations=False, no_pca=True, independent=True):
+    return OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode=hist_mode, no_pca=no_pca, layers=(LAYER,),
+                          independent=independent, fuse_rotations=fuse_rotations).to(device).eval()
 
 
 def pmc_traffic():
     """HBM-side bytes per launch per kernel class from the committed rocprofv3 PMC passes of this same command
     (profiles/pmc_traffic.json, produced by scripts/gpu_pmc_traffic.sh + scripts/summarize_pmc.py).  The counters cannot
-    be read from inside the process, so the numbers are those of the profiled run of the same workload."""
+    be read from inside the process, so the numbers are those of an EARLIER profiled run of the same workload, not of
+    this run: `traffic_source` in the JSON line names the file and what it was measured on."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return {}
+        return {}, None
     try:
-        return {k: v.get("hbm_bytes") for k, v in json.load(open(path))["kernels"].items()}
+        doc = json.load(open(path))
+        src = {"file": "profiles/pmc_traffic.json", "measured": doc.get("measured", "an earlier rocprofv3 --pmc run of bench.py"),
+               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); not measured in this run"}
+        return {k: v.get("hbm_bytes") for k, v in doc["kernels"].items()}, src
     except Exception:
-        return {}
+        return {}, None
 
 
 def roofline_of(name, rec, traffic=None):
@@ -167,7 +171,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="independent textures per GPU per step (16 / 32 / 64 measured: 176 / 183 / 198 textures/s)")
     ap.add_argument("--hist_mode", type=str, default="cdf", choices=["cdf", "sort", "chol", "pca", "sym"])
-    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused", help="one extra step each (N = 1 only); 'fused' = the re-associated rotation fast path")
+    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,refdefaults",
+                    help="one extra step each (N = 1 only); 'fused' = the labelled re-association fast paths, "
+                         "'refdefaults' = chol + PCA + pooled batch (the reference's own defaults)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
     ap.add_argument("--no_miopen_find", action="store_true", help="torch.backends.cudnn.benchmark = False: MIOpen picks the convolution kernels from its heuristics / find-db instead of timing every solver in the warm-up step")
@@ -219,6 +225,7 @@ def main():
         ops.profile_enable(False)
         prof = {} if args.no_kernel_timing else ops.profile_collect()
         assert torch.isfinite(out).all()
+    elapsed_local = elapsed
     elapsed = otdist.all_reduce_max(elapsed, device)
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
@@ -233,7 +240,9 @@ def main():
                    "textures_per_gpu_per_step": B, "hist_mode": args.hist_mode, "parallelism": f"textures x{world}",
                    "rotation_sharing": "one sequence per rank and step"},
     }
-    traffic = pmc_traffic()
+    traffic, traffic_source = pmc_traffic()
+    if traffic_source:
+        result["traffic_source"] = traffic_source
     if prof:
         kernels = sorted((roofline_of(k, v, traffic) for k, v in prof.items() if v["ms"] > 0),
                          key=lambda r: -r["avg_us"] * r["launches"])
@@ -242,8 +251,11 @@ def main():
         hot_ms = sum(v["ms"] for v in prof.values()) / args.steps
         result["hot_path_ms_per_step"] = round(hot_ms, 3)
         result["other_ms_per_step"] = round(ms_per_step - hot_ms, 3)  # VGG encode/decode, resizes, style encode, gaps
+    # per-rank step times: the driver's scaling record can then show WHERE a loss comes from (a slow rank, or all of them)
+    result["ms_per_step_by_rank"] = [round(1e3 * t / args.steps, 3) for t in otdist.all_gather_floats(elapsed_local, device)]
     if world > 1 and tex.style_sync is not None:
         result["style_broadcast_bytes_per_step"] = tex.style_sync.bytes_moved // (args.warmup + args.steps)
+        result["style_broadcast_messages_per_step"] = tex.style_sync.messages // (args.warmup + args.steps)
 
     if world == 1:
         by_mode = {args.hist_mode: round(value, 3)}
@@ -268,22 +280,48 @@ def main():
                           if k.startswith("sort") and v["ms"] > 0 and v["bytes"] > 0]
                     sk.sort(key=lambda r: -r["algorithmic_bytes"] * r["launches"])  # the pastiche match first
                     for r in sk:
+                        if r["kernel"] == "sort_match":
+                            # 12 B per element = read column 4 + read one source order statistic 4 + write column 4; the
+                            # source is the SHARED sorted style (L2-resident), so the compulsory HBM part is 8 of the 12
+                            r["achieved_compulsory_hbm"] = round(r["achieved"] * 8.0 / 12.0, 3)
+                            r["frac_compulsory_hbm"] = round(r["frac"] * 8.0 / 12.0, 4)
+                    for r in sk:
                         if r["kernel"] == "sort_columns":
                             r["note"] = ("the style's 256 columns, sorted once per iteration and shared by all textures: "
                                          "one launch of 256 workgroups, latency-bound by construction")
                     result["sort_kernels"] = sk
         result["textures_per_s_by_hist_mode"] = by_mode
-        if args.hist_mode in ("cdf", "sort") and "fused" in args.other_modes.split(","):
-            # labelled fast path, NOT the headline: (m @ R^T) @ R' re-associated to m @ (R^T R'), one GEMM per iteration
+        if "fused" in args.other_modes.split(","):
+            # labelled fast paths, NOT the headline.  cdf / sort: (m @ R^T) @ R' re-associated to m @ (R^T R'), one
+            # feature-map GEMM per iteration instead of two; chol: the whole step as one affine map in un-rotated space
+            # (SURVEY 7.4-2), one covariance + one feature-map GEMM instead of three
+            fused = {}
             with torch.inference_mode():
-                m = make_texturizer(args.hist_mode, device, fuse_rotations=True)
+                for mode in dict.fromkeys([args.hist_mode, "chol"]):
+                    m = make_texturizer(mode, device, fuse_rotations=True)
+                    m.rng = np.random.RandomState(1000)
+                    step(m)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    step(m)
+                    torch.cuda.synchronize()
+                    fused[mode] = round(B / (time.perf_counter() - t0), 3)
+            result["textures_per_s_fused_rotations"] = fused.get(args.hist_mode)
+            result["textures_per_s_fused_by_hist_mode"] = fused
+        if "refdefaults" in args.other_modes.split(","):
+            # the reference's own defaults for this layer: hist_mode chol, PCA on, --batch POOLED into one
+            # distribution (histmatch.py:11,17-18) — not like-for-like with the headline's independent textures
+            with torch.inference_mode():
+                m = make_texturizer("chol", device, no_pca=False, independent=False)
                 m.rng = np.random.RandomState(1000)
                 step(m)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 step(m)
                 torch.cuda.synchronize()
-                result["textures_per_s_fused_rotations"] = round(B / (time.perf_counter() - t0), 3)
+                result["textures_per_s_reference_defaults"] = {
+                    "value": round(B / (time.perf_counter() - t0), 3),
+                    "config": f"hist_mode=chol, PCA on, batch of {B} pooled into one distribution (reference --batch semantics)"}
         if not args.no_cpu_baseline:
             # more threads than ~32 only add oversubscription to torch-CPU convs and the OpenMP oracle (measured on the
             # 256-core GPU host: 256 threads were 5x slower than 8); `cores` reports what was actually used

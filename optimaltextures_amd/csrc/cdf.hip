@@ -362,7 +362,9 @@ static int launch_hist(const float* x, long ld, long ss, long n, int C, int x_n_
             return OPTEX_E_LAUNCH;
         }
     }
-    ProfScope prof(KC_HIST, st, 0.0, 4.0 * (double)n * ncols);
+    // algorithmic bytes: every DISTINCT column once — a shared source (x_n_seg == 1) is binned with each target segment's
+    // range (n_seg blocks per channel re-read it through L2) but comes from HBM once
+    ProfScope prof(KC_HIST, st, 0.0, 4.0 * (double)n * C * (x_n_seg == 1 ? 1 : n_seg));
     hipLaunchKernelGGL(col_hist_kernel, dim3(ncols, chunks < 1 ? 1 : chunks), dim3(256), 0, st, x, ld, ss, n, C,
                        x_n_seg, chunk, lo, hi, hist, vec);
     return check_launch("col_hist_kernel");

@@ -40,6 +40,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     const int seg = L / (a.tiles_m * a.tiles_n);
     const int m0 = tm_idx * BM;
     const long n0 = (long)tn_idx * BN;
+    const bool sym = !OPM && !BPM && BM == BN && a.sym;
+    if (sym && (long)m0 > n0) return;  // the mirror image of a tile above the diagonal (uniform for the block)
 
     const float* __restrict__ At = a.At + (size_t)seg * a.at_ss;
     const float* __restrict__ Bp = a.B + (size_t)seg * a.b_ss;
@@ -208,6 +210,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
                             const float d = Cp[off] - v;
                             const float sd = strength * d;
                             v = v + sd;
+                        }
+                        if (sym) {  // diagonal tiles hold both (m, i) and (i, m): keep the upper one
+                            if ((long)m <= nn) {
+                                Op[off] = v;
+                                if (nn < a.M) Op[(size_t)nn * a.ldo + m] = v;
+                            }
+                            continue;
                         }
                         Op[off] = v;
                     }
@@ -410,6 +419,7 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
 template <bool BPM, bool OPM>
 static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
+    if (a.sym) return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);  // square tiles: the mirrored store needs BM == BN
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
         if (!BPM && !OPM && vec && gemm_mfma16_env() && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 && a.M > 128 &&
@@ -475,6 +485,6 @@ extern "C" int optex_gemm_tn(const float* At, long lda, long at_seg_stride, cons
     a.bsub = bsub; a.bsub_ss = bsub_seg_stride;
     a.badd = badd; a.badd_ss = badd_seg_stride;
     a.content = content; a.strength = strength;
-    a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.prof_cls = KC_GEMM;
+    a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.sym = 0; a.prof_cls = KC_GEMM;
     return gemm_tn_launch(a, b_layout, o_layout, as_stream(stream));
 }

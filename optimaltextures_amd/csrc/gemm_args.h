@@ -17,7 +17,10 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     // optional scaling epilogue of the small C x C products of the linear modes (linalg.hip), channel-major output only:
     //   OUT = alpha * alpha_seg[seg] * acc + diag * (m == i)        (epi = 0: untouched, the hot-loop arithmetic)
-    int epi; float alpha; const float* alpha_seg; float diag;
+    // sym = 1 (64 x 64 tiles, square output): the product is symmetric in exact arithmetic — only the tiles on or above
+    // the diagonal are computed and every element is stored together with its mirror image, so the output is EXACTLY
+    // symmetric (half the flops; what keeps the Newton-Schulz iteration of linalg.hip on its stable branch).
+    int epi; float alpha; const float* alpha_seg; float diag; int sym;
     int prof_cls;  // KC_GEMM for the feature-map GEMMs, KC_SMALL_GEMM for the C x C products of linalg.hip
 };
 

@@ -22,8 +22,9 @@ namespace optex {
 
 // ------------------------------------------------------------------------------------------------ small batched products
 // OUT[b] = alpha * alpha_seg[b] * (At[b]^T @ B[b]) + diag * I   for `batch` C x C matrices (strides in elements, 0 = shared)
+// sym: the product is symmetric in exact arithmetic -> upper tiles only, stored with their mirror image (exactly symmetric)
 int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, long b_ss, float* O, long ldo, long o_ss, int C,
-               int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st) {
+               int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st, bool sym) {
     GemmArgs a;
     a.At = At; a.lda = lda; a.at_ss = at_ss;
     a.B = B; a.ldb = ldb; a.b_ss = b_ss;
@@ -31,6 +32,7 @@ int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, 
     a.M = C; a.K = C; a.n = C; a.n_seg = batch;
     a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
     a.epi = epi ? 1 : 0; a.alpha = alpha; a.alpha_seg = alpha_seg; a.diag = diag;
+    a.sym = sym ? 1 : 0;
     a.prof_cls = KC_SMALL_GEMM;
     return gemm_tn_launch(a, OPTEX_CHANNEL_MAJOR, OPTEX_CHANNEL_MAJOR, st);
 }
@@ -93,9 +95,7 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const float* __restrict_
             const float* src = roleL ? Ub : Wb;
             // W[i][k] = 0 for k < i: a wave of W rows starts at its first row
             const int k_beg = roleL ? 0 : wave_first;
-#pragma unroll 4
-            for (int k = k_beg; k < j0; k++) {
-                const float v = src[(size_t)k * NP + r];
+            auto axpy = [&](float v, int k) {
                 const float4* p = reinterpret_cast<const float4*>(pan + k * CH_NB);
 #pragma unroll
                 for (int q = 0; q < CH_NB / 4; q++) {
@@ -105,7 +105,17 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const float* __restrict_
                     acc[4 * q + 2] = __builtin_fmaf(-v, l.z, acc[4 * q + 2]);
                     acc[4 * q + 3] = __builtin_fmaf(-v, l.w, acc[4 * q + 3]);
                 }
+            };
+            // the finished columns come back from L2: eight independent loads in flight per thread before the first use
+            int k = k_beg;
+            for (; k + 8 <= j0; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = src[(size_t)(k + u) * NP + r];
+#pragma unroll
+                for (int u = 0; u < 8; u++) axpy(v[u], k + u);
             }
+            for (; k < j0; k++) axpy(src[(size_t)k * NP + r], k);
         }
         // ---- phase B: the panel itself, column by column (the pivot row publishes its entries through dg)
         float x[CH_NB];
@@ -231,10 +241,14 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float* buf, float** You
     const int K = ns_iterations();
     for (int k = 0; k < K; k++) {
         const bool last = k == K - 1;
-        // W = 1.5 I - 0.5 Z Y      (all iterates are polynomials in A: symmetric and commuting, so At^T B == At B)
-        if ((rc = small_gemm(Z, C, cc, Y, C, cc, W, C, cc, C, batch, true, -0.5f, nullptr, 1.5f, st))) return rc;
-        if ((rc = small_gemm(Y, C, cc, W, C, cc, Y2, C, cc, C, batch, last, 1.f, last ? rs : nullptr, 0.f, st))) return rc;
-        if ((rc = small_gemm(W, C, cc, Z, C, cc, Z2, C, cc, C, batch, last, 1.f, last ? irs : nullptr, 0.f, st))) return rc;
+        // W = 1.5 I - 0.5 Z Y.  All iterates are polynomials in A, i.e. symmetric and commuting in exact arithmetic; the
+        // GEMM computes At^T B, and with iterates that are only ALMOST symmetric (fp32 round-off) that transposed
+        // variant of the iteration amplifies the antisymmetric part by ~1.6x per step (measured) instead of damping
+        // it.  Storing every product with its mirror image (sym) keeps Y, Z, W exactly symmetric: At^T B == At B, the
+        // stable coupled iteration, for half the flops.
+        if ((rc = small_gemm(Z, C, cc, Y, C, cc, W, C, cc, C, batch, true, -0.5f, nullptr, 1.5f, st, true))) return rc;
+        if ((rc = small_gemm(Y, C, cc, W, C, cc, Y2, C, cc, C, batch, last, 1.f, last ? rs : nullptr, 0.f, st, true))) return rc;
+        if ((rc = small_gemm(W, C, cc, Z, C, cc, Z2, C, cc, C, batch, last, 1.f, last ? irs : nullptr, 0.f, st, true))) return rc;
         float* t = Y; Y = Y2; Y2 = t;
         t = Z; Z = Z2; Z2 = t;
     }
@@ -331,23 +345,23 @@ extern "C" int optex_transfer_operator(int mode, const float* cov_t, const float
     if (mode == 2) {  // histmatch.py:24-27
         if ((rc = launch_chol_inv(cov_s, (long)cc, C, Ss, w.Us, w.Ls, st))) return rc;
         if ((rc = launch_chol_inv(cov_t, (long)cc, C, n_seg, w.Ut, w.Lt, st))) return rc;
-        return small_gemm(w.Lt, NP, (long)pp, w.Us, NP, Ss > 1 ? (long)pp : 0, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+        return small_gemm(w.Lt, NP, (long)pp, w.Us, NP, Ss > 1 ? (long)pp : 0, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
     }
     float *Y, *Z;
     if (mode == 3) {  // histmatch.py:29-34
         if ((rc = ns_sqrt(cov_s, (long)cc, C, Ss, w.ns_buf, &Y, &Z, st))) return rc;
         if ((rc = dcopy(w.Ys, Y, Ss * cc, st))) return rc;
         if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
-        return small_gemm(Z, C, (long)cc, w.Ys, C, Ss > 1 ? (long)cc : 0, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+        return small_gemm(Z, C, (long)cc, w.Ys, C, Ss > 1 ? (long)cc : 0, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
     }
     // histmatch.py:36-42
     if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
     if ((rc = dcopy(w.Yt, Y, n_seg * cc, st))) return rc;
     if ((rc = dcopy(w.Zt, Z, n_seg * cc, st))) return rc;
-    if ((rc = small_gemm(cov_s, C, Ss > 1 ? (long)cc : 0, w.Yt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+    if ((rc = small_gemm(cov_s, C, Ss > 1 ? (long)cc : 0, w.Yt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
         return rc;
-    if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st))) return rc;
+    if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, true))) return rc;
     if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
-    if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st))) return rc;
-    return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+    if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false))) return rc;
+    return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
 }

@@ -15,7 +15,7 @@ using namespace optex;
 
 namespace optex {
 int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, long b_ss, float* O, long ldo, long o_ss, int C,
-               int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st);
+               int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st, bool sym);
 __global__ void rot_mean_kernel(const float* __restrict__ R, const float* __restrict__ mu, int C, int per, float* __restrict__ out);
 int chol_np(int C);
 int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st);
@@ -145,27 +145,27 @@ int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg
         if ((rc = launch_chol_inv(cov_t, (long)cc, C, n_seg, w.Ut, w.Lt, st))) return rc;
         const float* Us = w.Us + (size_t)it * Ss * pp;
         return small_gemm(w.Lt, NP, (long)pp, Us, NP, Ss > 1 ? (long)pp : 0, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr,
-                          0.f, st);
+                          0.f, st, false);
     }
     float *Y, *Z;
     if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
     if (mode == MODE_PCA) {
         // histmatch.py:29-34  T = Q_s Q_t^-1  ->  T^T = Q_t^-1 Q_s   (both symmetric)
         const float* Ys = w.Ys + (size_t)it * Ss * cc;
-        return small_gemm(Z, C, (long)cc, Ys, C, Ss > 1 ? (long)cc : 0, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+        return small_gemm(Z, C, (long)cc, Ys, C, Ss > 1 ? (long)cc : 0, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
     }
     // histmatch.py:36-42  T = Q_t^-1 (Q_t S_s Q_t)^1/2 Q_t^-1   (symmetric: T^T = T)
     if ((rc = copy_async(w.Yt, Y, (size_t)n_seg * cc, st))) return rc;
     if ((rc = copy_async(w.Zt, Z, (size_t)n_seg * cc, st))) return rc;
     const float* Cs = w.cov_sr + (size_t)it * Ss * cc;
-    if ((rc = small_gemm(Cs, C, Ss > 1 ? (long)cc : 0, w.Yt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+    if ((rc = small_gemm(Cs, C, Ss > 1 ? (long)cc : 0, w.Yt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
         return rc;                                                                    // S_s Q_t
-    if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+    if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, true)))
         return rc;                                                                    // Q_t S_s Q_t
     if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;     // its square root
-    if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+    if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
         return rc;                                                                    // (.)^1/2 Q_t^-1
-    return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st);
+    return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
 }
 
 // style statistics once, rotated for every iteration:  cov_sr[it][s] = R_it^T cov(S_s) R_it + eps I,  mu_sr = R_it^T mu_s,
@@ -179,10 +179,10 @@ int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int 
     for (int s = 0; s < Ss; s++) {
         // tmp[it][s] = cov_s @ R_it   (cov_s symmetric);   cov_sr[it][s] = R_it^T @ tmp + eps I
         if ((rc = small_gemm(w.cov_s + (size_t)s * cc, C, 0, R32, C, (long)cc, w.tmp_s + (size_t)s * cc, C, (long)(cc * Ss), C, iters,
-                             false, 1.f, nullptr, 0.f, st)))
+                             false, 1.f, nullptr, 0.f, st, false)))
             return rc;
         if ((rc = small_gemm(R32, C, (long)cc, w.tmp_s + (size_t)s * cc, C, (long)(cc * Ss), w.cov_sr + (size_t)s * cc, C,
-                             (long)(cc * Ss), C, iters, true, 1.f, nullptr, kEps, st)))
+                             (long)(cc * Ss), C, iters, true, 1.f, nullptr, kEps, st, true)))
             return rc;
     }
     hipLaunchKernelGGL(rot_mean_kernel, dim3(iters * Ss), dim3(256), 0, st, R32, w.mu_s, C, Ss, w.mu_sr);
@@ -226,14 +226,14 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
             // one covariance and ONE feature-map GEMM per iteration instead of three.  small_gemm(L, B) = L^T @ B.
             if ((rc = optex_linear_stats(cur, n, xs, n, C, n_seg, 0, 0.f, w.mu_x, w.cov_t, w.stats_ws, w.stats_ws_bytes, stream)))
                 return rc;
-            if ((rc = small_gemm(w.cov_t, C, (long)cc, R, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+            if ((rc = small_gemm(w.cov_t, C, (long)cc, R, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
                 return rc;                                                                   // cov(x) R
-            if ((rc = small_gemm(R, C, 0, w.M1, C, (long)cc, w.Mt, C, (long)cc, C, n_seg, true, 1.f, nullptr, kEps, st)))
+            if ((rc = small_gemm(R, C, 0, w.M1, C, (long)cc, w.Mt, C, (long)cc, C, n_seg, true, 1.f, nullptr, kEps, st, true)))
                 return rc;                                                                   // R^T cov(x) R + eps I
             if ((rc = transfer_operators(mode, w, w.Mt, C, n_seg, Ss, it, st))) return rc;   // At = T^T
-            if ((rc = small_gemm(w.At, C, (long)cc, Rt, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+            if ((rc = small_gemm(w.At, C, (long)cc, Rt, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
                 return rc;                                                                   // (T^T)^T R^T = T R^T
-            if ((rc = small_gemm(w.M1, C, (long)cc, Rt, C, 0, w.Mt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st)))
+            if ((rc = small_gemm(w.M1, C, (long)cc, Rt, C, 0, w.Mt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
                 return rc;                                                                   // (T R^T)^T R^T = R T^T R^T = M^T
             // x' = M (x - mu_x) + mu_s  (R mu_sr = R R^T mu_s = the un-rotated style mean), content blend in the epilogue
             if ((rc = fgemm(w.Mt, (long)cc, cur, nxt, C, n, n_seg, w.mu_x, w.mu_s, Ss > 1 ? C : 0, content, strength, stream)))

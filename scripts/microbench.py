@@ -84,6 +84,20 @@ def main():
         report(tag + "_sort_match", timed(lambda: ops.sort_match_seg(Seg.of(y), Seg.of(ys), out=Seg.of(out)), reps=5))
         # tie-heavy variant: un-rotated ReLU features (about half the keys are exactly 0)
         report(tag + "_sort_kv_ties", timed(lambda: ops.sort_columns(x), reps=5))
+    if "sortmatch" in only and n <= 16384:  # the match on the hot path alone (PMC passes: one kernel class per run)
+        out = torch.empty_like(y)
+        report(tag + "_sort_match", timed(lambda: ops.sort_match_seg(Seg.of(y), Seg.of(ys), out=Seg.of(out))))
+    if "linalg" in only:
+        _, cov = ops.linear_stats(Seg.of(y), pool=False)
+        _, cov_s = ops.linear_stats(Seg.of(ys), pool=False)
+        report(tag + "_chol_inv", timed(lambda: ops.chol_inv(cov), reps=10))
+        report(tag + "_spd_sqrt", timed(lambda: ops.spd_sqrt(cov), reps=5))
+        for mode in ("chol", "pca", "sym"):
+            report(tag + "_transfer_" + mode, timed(lambda: ops.transfer_operator_t(cov, cov_s, mode), reps=5))
+            xx = x.clone()
+            report(tag + "_loop_" + mode, timed(lambda: ops.ot_loop(mode, xx, style, R32, Rt32), reps=2, warm=1))
+            xx = x.clone()
+            report(tag + "_loop_fused_" + mode, timed(lambda: ops.ot_loop(mode, xx, style, R32, Rt32, fuse_rotations=True), reps=2, warm=1))
     if "linear" in only:
         report(tag + "_linear", timed(lambda: ops.linear_stats(Seg.of(y), pool=False), reps=5))
     if "glue" in only:

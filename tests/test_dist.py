@@ -145,3 +145,76 @@ def test_driver_style_prefetch_gloo_world2():
         for x, y in zip(fa, fb):
             assert x.shape == y.shape and x.shape[1] == 64 and np.array_equal(x, y)   # rank 1 holds rank 0's features
     assert a[0][1][0].shape[2] == a[0][3][0][0] * a[0][3][0][1]      # [1, C, Hs * Ws] and its (Hs, Ws)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's step() over gloo
+def _oracle_backed_ops():
+    """Stand-ins for the two GPU entry points the driver's forward() needs, built from the CPU oracle, so that the
+    ORCHESTRATION (style prefetch + packed broadcast + per-rank textures) can run under gloo without a GPU.  Test
+    infrastructure only: the product path never routes through the oracle."""
+    from oracle import oracle as orc
+    from optimaltextures_amd import ops, rotation
+
+    def rotations(N, count, device, rng=None, want64=False):
+        normals = rotation.draw_normals(N, count, rng)
+        R = np.stack([orc.random_rotation_from_normals(normals[i], N) for i in range(count)]).astype(np.float32)
+        return torch.from_numpy(R), torch.from_numpy(np.ascontiguousarray(R.transpose(0, 2, 1)))
+
+    def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False):
+        xs, st = x.numpy(), style.numpy()
+        for s in range(xs.shape[0]):
+            w = xs[s]
+            for R in R32.numpy():
+                w = orc.unrotate_cm(orc.hist_match_cm(orc.rotate_cm(w, R), 1, orc.rotate_cm(st[s if st.shape[0] > 1 else 0], R), 1,
+                                                      mode), R)
+            xs[s] = w
+        return x
+
+    rotation.rotations = rotations
+    ops.ot_loop = ot_loop
+
+
+def _bench_step_job(rank, world, device):
+    """what bench.py's step() does on every rank: B independent textures, relu-layer encode -> OT iterations -> decode over
+    the multi-resolution passes, the style side arriving from rank 0 through StyleSync (ranks != 0 hold a blank style)"""
+    from optimaltextures_amd.driver import OptimalTexture
+    _oracle_backed_ops()
+    tex = OptimalTexture(size=288, iters=20, passes=2, hist_mode="cdf", no_pca=True, layers=(1,), independent=True).eval()
+    tex.rng = np.random.RandomState(1000 + rank)
+    if world > 1:
+        tex.style_sync = otdist.StyleSync(device)
+    g = torch.Generator().manual_seed(77)
+    style = torch.rand(1, 3, 64, 96, generator=g)
+    if world > 1 and rank != 0:
+        style = torch.zeros_like(style)          # only the source rank's style may matter
+    pastiche = torch.rand(2, 3, 288, 288, generator=torch.Generator().manual_seed(rank))
+    with torch.inference_mode():
+        out = tex.forward(pastiche, [style])
+    sync = tex.style_sync
+    return out.numpy().copy(), (sync.messages, sync.bytes_moved) if sync is not None else (0, 0)
+
+
+def test_bench_step_with_style_sync_gloo_world2():
+    """Both ranks run the whole forward() with the packed style broadcast; rank 1 (blank local style) must produce exactly
+    what a single process computes for rank 1's seeds with the real style: the broadcast delivered rank 0's style side for
+    every pass, and nothing else crossed ranks.  One exchange per forward call = 2 messages."""
+    res = run_world(_bench_step_job, 2)
+    (out0, (msgs0, bytes0)), (out1, (msgs1, bytes1)) = res[0], res[1]
+    assert msgs0 == msgs1 == 2 and bytes0 == bytes1 > 0
+    assert out0.shape == out1.shape == (2, 3, 288, 288) and np.isfinite(out0).all() and np.isfinite(out1).all()
+    assert not np.array_equal(out0, out1)                      # different seeds per rank: different textures
+
+    ref = run_world(_single_rank1_job, 1)[0]
+    assert np.array_equal(out1, ref)
+
+
+def _single_rank1_job(rank, world, device):
+    """rank 1's work in a world of one: real style, seeds of rank 1"""
+    from optimaltextures_amd.driver import OptimalTexture
+    _oracle_backed_ops()
+    tex = OptimalTexture(size=288, iters=20, passes=2, hist_mode="cdf", no_pca=True, layers=(1,), independent=True).eval()
+    tex.rng = np.random.RandomState(1001)
+    style = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(77))
+    pastiche = torch.rand(2, 3, 288, 288, generator=torch.Generator().manual_seed(1))
+    with torch.inference_mode():
+        return tex.forward(pastiche, [style]).numpy().copy()
