@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 3
+#define OPTEX_ABI_VERSION 4
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -124,21 +124,22 @@ int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, 
  *     U [batch, ld, ld] = L^T (upper), Linv [batch, ld, ld] = L^-1 (lower), ld = optex_chol_ld(C) = C rounded up to 32
  *     (zero outside the triangle, identity in the padding).  C <= 512.
  *   optex_spd_sqrt:  Y = A^1/2, Z = A^-1/2 of symmetric positive definite matrices — the `eve @ sqrt(diag(eva)) @ eve.T`
- *     of histmatch.py:30-31,33,37,40 and its inverse, by the coupled Newton-Schulz iteration (GEMMs only; the spectrum
- *     is bounded below by eps = 1).  Y, Z [batch, C, C] contiguous, either may be NULL.
+ *     of histmatch.py:30-31,33,37,40 and its inverse, by the scaled coupled Newton-Schulz iteration (GEMMs only).
+ *     lambda_min: a lower bound of the spectrum (the eps of `cov + eps * I`; <= 0 if unknown) — it sets the scaling;
+ *     fp32 round-off is reached for |A|_F / lambda_min <= 1e7.  Y, Z [batch, C, C] contiguous, either may be NULL.
  *   optex_transfer_operator:  Tt[s] = T_s^T with  matched = T @ hist_t  for mode 2 = chol (L_s L_t^-1), 3 = pca
  *     (Q_s Q_t^-1), 4 = sym (Q_t^-1 (Q_t S_s Q_t)^1/2 Q_t^-1);  cov_t [n_seg, C, C], cov_s [src_n_seg in {1, n_seg}, C, C]
- *     (both with eps * I already added, as optex_linear_stats returns them), Tt [n_seg, C, C] — the `At` operand of
- *     optex_gemm_tn for the apply step.
+ *     (both with eps * I already added, as optex_linear_stats returns them; eps is passed again as the spectrum bound of
+ *     optex_spd_sqrt), Tt [n_seg, C, C] — the `At` operand of optex_gemm_tn for the apply step.
  * ------------------------------------------------------------------------------------------------- */
 int optex_chol_ld(int C);
 int optex_chol_inv(const float* A, long a_seg_stride, int C, int batch, float* U, float* Linv, void* stream);
 size_t optex_spd_sqrt_ws_bytes(int C, int batch);
-int optex_spd_sqrt(const float* A, long a_seg_stride, int C, int batch, float* Y, float* Z, void* ws, size_t ws_bytes,
-                   void* stream);
+int optex_spd_sqrt(const float* A, long a_seg_stride, int C, int batch, float lambda_min, float* Y, float* Z, void* ws,
+                   size_t ws_bytes, void* stream);
 size_t optex_transfer_operator_ws_bytes(int mode, int C, int n_seg, int src_n_seg);
-int optex_transfer_operator(int mode, const float* cov_t, const float* cov_s, int C, int n_seg, int src_n_seg, float* Tt,
-                            void* ws, size_t ws_bytes, void* stream);
+int optex_transfer_operator(int mode, const float* cov_t, const float* cov_s, int C, int n_seg, int src_n_seg, float eps,
+                            float* Tt, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * R0  rotation generator, optex.py:142-149 -> scipy.stats.special_ortho_group.rvs (Householder chain, fp64).

@@ -7,7 +7,7 @@ import torch  # imported BEFORE the CDLL so the library binds to the HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liboptex_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 CHANNEL_MAJOR, PIXEL_MAJOR = 0, 1
 
 _c = ctypes
@@ -33,9 +33,9 @@ SIGNATURES = {
     "optex_chol_ld": (_I, [_I]),
     "optex_chol_inv": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "optex_spd_sqrt_ws_bytes": (_SZ, [_I, _I]),
-    "optex_spd_sqrt": (_I, [_P, _L, _I, _I, _P, _P, _P, _SZ, _P]),
+    "optex_spd_sqrt": (_I, [_P, _L, _I, _I, _F, _P, _P, _P, _SZ, _P]),
     "optex_transfer_operator_ws_bytes": (_SZ, [_I, _I, _I, _I]),
-    "optex_transfer_operator": (_I, [_I, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
+    "optex_transfer_operator": (_I, [_I, _P, _P, _I, _I, _I, _F, _P, _P, _SZ, _P]),
     "optex_rotation_normals": (_L, [_I]),
     "optex_rotation_ws_bytes": (_SZ, [_I, _I]),
     "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     const float* __restrict__ Cp = a.content ? a.content + (size_t)seg * a.o_ss : nullptr;
     const float* __restrict__ badd = a.badd ? a.badd + (size_t)seg * a.badd_ss : nullptr;
     const float strength = a.strength;
-    const bool epi = !OPM && a.epi;
+    const bool epi = a.epi;
     const float alpha = epi ? (a.alpha_seg ? a.alpha * a.alpha_seg[seg] : a.alpha) : 1.f;
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
@@ -229,6 +229,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         v[q] = acc[tm][tn][g * 4 + q];
+                        if (epi) {
+                            v[q] = v[q] * alpha;
+                            if ((long)(m + q) == nn) v[q] = v[q] + a.diag;
+                        }
                         if (badd && m + q < a.M) v[q] = v[q] + badd[m + q];
                     }
                     const size_t off = (size_t)nn * a.ldo + m;

@@ -5,12 +5,12 @@
 //   chol  T = L_s L_t^-1        chol_inv_kernel: one workgroup per matrix, left-looking blocked Cholesky that carries
 //                               the rows of L^-T along as extra right-hand sides, so L^T (= U) and L^-1 come out of one
 //                               pass; T^T = (L_t^-1)^T U_s is one batched C x C GEMM on the MFMA kernel of gemm.hip.
-//   pca   T = S_s^1/2 S_t^-1/2  coupled Newton-Schulz iteration  Y <- Y W, Z <- W Z, W = (3 I - Z Y) / 2  from
-//   sym   T = S_t^-1/2 (S_t^1/2 S_s S_t^1/2)^1/2 S_t^-1/2        Y0 = A / |A|_F, Z0 = I:  Y -> (A/|A|_F)^1/2, Z -> its inverse.
+//   pca   T = S_s^1/2 S_t^-1/2  scaled coupled Newton-Schulz iteration  Y <- a Y W, Z <- a W Z, W = (3 I - a^2 Z Y) / 2
+//   sym   T = S_t^-1/2 (S_t^1/2 S_s S_t^1/2)^1/2 S_t^-1/2        from Y0 = A / |A|_F, Z0 = I:  Y -> (A/|A|_F)^1/2, Z -> its inverse.
 //                               Only GEMMs (MFMA-shaped work, batched over all segments) instead of a batched symmetric
 //                               eigensolver: the reference's Q = V sqrt(L) V^T (histmatch.py:30-31) IS the principal
-//                               square root, and eps = 1 bounds the spectrum below by 1, so |A|_F / lambda_min stays in
-//                               the hundreds for VGG features and the iteration reaches fp32 round-off in <= 12 steps.
+//                               square root, and eps bounds the spectrum below, which is what the scaling needs to
+//                               reach fp32 round-off in 12 steps for |A|_F / lambda_min up to 1e7.
 //
 // Everything is fp32 like the reference's LAPACK calls; agreement with the reference is by tolerance (1e-4 per step,
 // SURVEY 8c), not bit-exact — summation orders differ.
@@ -176,9 +176,43 @@ int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float
 }
 
 // ------------------------------------------------------------------------------------------------ Newton-Schulz square roots
-// Y0 = A / |A|_F, Z0 = I;  rs = sqrt(|A|_F), irs = 1 / rs  (the scale comes back in the last iteration's epilogue)
-__global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ A, long a_ss, int C, float* __restrict__ Y,
-                                                      float* __restrict__ Z, float* __restrict__ rs, float* __restrict__ irs) {
+// Coupled iteration (Higham, "Stable iterations for the matrix square root", 1997) with the interval scaling of
+// Chen & Chow ("A stable scaling of Newton-Schulz for improving the sign function computation of a Hermitian matrix", 2014):
+//   Y0 = A / |A|_F, Z0 = I;   W = (3 I - a^2 Z Y) / 2,  Y <- a Y W,  Z <- a W Z;   Y -> (A/|A|_F)^1/2, Z -> its inverse.
+// The eigenvalues of Z Y start in [l0^2, 1] with l0^2 = lambda_min / |A|_F, and a_k = sqrt(3 / (1 + l + l^2)),
+// l <- a l (3 - a^2 l^2) / 2 maps [l, 1] onto [l', 1] with l' ~ 2.6 l: 10 iterations reach fp32 round-off from
+// |A|_F / lambda_min = 1e5, 12 from 1e7 (plain Newton-Schulz, a = 1: 20 and > 30).  Once l = 1 the scaling is 1 and
+// further iterations sit on the (stable) fixed point, so a fixed count is safe for every better conditioned matrix.
+//
+// The products are TRUE products in the order above (small_gemm_nn): the iteration is stable only as long as Y and Z
+// commute with W the way exact polynomials in A do.  Measured in fp32: evaluating Y^T W / W^T Z instead (what the
+// transposing GEMM gives for free), or storing every product with its mirror image, amplifies the round-off
+// asymmetry by 1.6-10x per iteration and diverges for |A|_F / lambda_min > 1e3.
+constexpr int NS_MAX_ITERS = 64;
+
+// A @ B for `batch` C x C row-major matrices on the MFMA kernel of gemm.hip, which evaluates At^T @ Bm:
+// (A B)^T = B^T A^T, so At := B, Bm := A read "pixel-major" (element (k, i) at i * ld + k) and the result stored
+// pixel-major (transposed back).  OUT = alpha * alpha_seg[b] * (A B) + diag * I.
+int small_gemm_nn(const float* A, const float* B, float* O, int C, int batch, float alpha, const float* alpha_seg, float diag,
+                  hipStream_t st) {
+    const long cc = (long)C * C;
+    GemmArgs a;
+    a.At = B; a.lda = C; a.at_ss = cc;
+    a.B = A; a.ldb = C; a.b_ss = cc;
+    a.O = O; a.ldo = C; a.o_ss = cc;
+    a.M = C; a.K = C; a.n = C; a.n_seg = batch;
+    a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
+    a.epi = 1; a.alpha = alpha; a.alpha_seg = alpha_seg; a.diag = diag; a.sym = 0;
+    a.prof_cls = KC_SMALL_GEMM;
+    return gemm_tn_launch(a, OPTEX_PIXEL_MAJOR, OPTEX_PIXEL_MAJOR, st);
+}
+
+// Y0 = A / |A|_F, Z0 = I, and the per-matrix coefficients of all K iterations:
+//   cw[k][b] = a_k^2   (W = 1.5 I - 0.5 cw Z Y),   cy[k][b] = a_k (x sqrt|A|_F in the last iteration),
+//   cz[k][b] = a_k (/ sqrt|A|_F in the last iteration) — the scale of A comes back in the last epilogue.
+__global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ A, long a_ss, int C, int batch, int K,
+                                                      float lambda_min, float* __restrict__ Y, float* __restrict__ Z,
+                                                      float* __restrict__ cw, float* __restrict__ cy, float* __restrict__ cz) {
     const int b = blockIdx.x;
     const float* Ab = A + (size_t)b * a_ss;
     const size_t cc = (size_t)C * C;
@@ -193,11 +227,24 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float fro = (float)sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
-        fro_s = fro;
-        const float r = sqrtf(fro);
-        rs[b] = r;
-        irs[b] = __fdiv_rn(1.f, r);
+        const double fro = sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        fro_s = (float)fro;
+        // lower end of the spectrum of Z0 Y0 = A / |A|_F; without a bound from the caller: fp32 cannot resolve
+        // eigenvalues below ~2^-23 |A|_F anyway
+        double l2 = lambda_min > 0.f ? (double)lambda_min / fro : 0.0;
+        if (l2 < 1.2e-7) l2 = 1.2e-7;
+        if (l2 > 1.0) l2 = 1.0;
+        double l = sqrt(l2);
+        const double r = sqrt((double)fro_s);
+        for (int k = 0; k < K; k++) {
+            const double a = sqrt(3.0 / (1.0 + l + l * l));
+            l = a * l * (3.0 - a * a * l * l) * 0.5;
+            if (l > 1.0) l = 1.0;
+            const bool last = k == K - 1;
+            cw[(size_t)k * batch + b] = (float)(a * a);
+            cy[(size_t)k * batch + b] = (float)(last ? a * r : a);
+            cz[(size_t)k * batch + b] = (float)(last ? a / r : a);
+        }
     }
     __syncthreads();
     const float fro = fro_s;
@@ -212,43 +259,39 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
 int ns_iterations() {
     static const int v = [] {
         const char* e = getenv("OPTEX_NS_ITERS");
-        const int k = e ? atoi(e) : 16;
-        return k < 2 ? 2 : (k > 64 ? 64 : k);
+        const int k = e ? atoi(e) : 12;
+        return k < 2 ? 2 : (k > NS_MAX_ITERS ? NS_MAX_ITERS : k);
     }();
     return v;
 }
 
-// Principal square root and inverse square root of `batch` symmetric positive definite C x C matrices.
-// buf: 6 * batch * C * C floats (Y, Z, W and their ping-pong partners) + 2 * batch floats.  The results land in
-// *Yout / *Zout (pointers into buf).
-size_t ns_ws_floats(int C, int batch) { return (size_t)6 * batch * C * C + 2 * (size_t)batch + 64; }
+// Principal square root and inverse square root of `batch` symmetric positive definite C x C matrices whose spectrum
+// is bounded below by lambda_min (<= 0: unknown).  buf: ns_ws_floats(C, batch) floats (Y, Z, W, their ping-pong
+// partners and the coefficient tables).  The results land in *Yout / *Zout (pointers into buf).
+size_t ns_ws_floats(int C, int batch) { return (size_t)5 * batch * C * C + (size_t)3 * NS_MAX_ITERS * batch + 64; }
 
-int ns_sqrt(const float* A, long a_ss, int C, int batch, float* buf, float** Yout, float** Zout, hipStream_t st) {
+int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float* buf, float** Yout, float** Zout, hipStream_t st) {
     const size_t cc = (size_t)C * C, sz = cc * batch;
     float* Y = buf;
     float* Z = buf + sz;
     float* W = buf + 2 * sz;
     float* Y2 = buf + 3 * sz;
     float* Z2 = buf + 4 * sz;
-    float* rs = buf + 6 * sz;
-    float* irs = rs + batch;
+    const int K = ns_iterations();
+    float* cw = buf + 5 * sz;
+    float* cy = cw + (size_t)NS_MAX_ITERS * batch;
+    float* cz = cy + (size_t)NS_MAX_ITERS * batch;
     {
         ProfScope prof(KC_NS_INIT, st, 0.0, 12.0 * (double)cc * batch);
-        hipLaunchKernelGGL(ns_init_kernel, dim3(batch), dim3(256), 0, st, A, a_ss, C, Y, Z, rs, irs);
+        hipLaunchKernelGGL(ns_init_kernel, dim3(batch), dim3(256), 0, st, A, a_ss, C, batch, K, lambda_min, Y, Z, cw, cy, cz);
     }
     int rc = check_launch("ns_init_kernel");
     if (rc) return rc;
-    const int K = ns_iterations();
     for (int k = 0; k < K; k++) {
-        const bool last = k == K - 1;
-        // W = 1.5 I - 0.5 Z Y.  All iterates are polynomials in A, i.e. symmetric and commuting in exact arithmetic; the
-        // GEMM computes At^T B, and with iterates that are only ALMOST symmetric (fp32 round-off) that transposed
-        // variant of the iteration amplifies the antisymmetric part by ~1.6x per step (measured) instead of damping
-        // it.  Storing every product with its mirror image (sym) keeps Y, Z, W exactly symmetric: At^T B == At B, the
-        // stable coupled iteration, for half the flops.
-        if ((rc = small_gemm(Z, C, cc, Y, C, cc, W, C, cc, C, batch, true, -0.5f, nullptr, 1.5f, st, true))) return rc;
-        if ((rc = small_gemm(Y, C, cc, W, C, cc, Y2, C, cc, C, batch, last, 1.f, last ? rs : nullptr, 0.f, st, true))) return rc;
-        if ((rc = small_gemm(W, C, cc, Z, C, cc, Z2, C, cc, C, batch, last, 1.f, last ? irs : nullptr, 0.f, st, true))) return rc;
+        const size_t o = (size_t)k * batch;
+        if ((rc = small_gemm_nn(Z, Y, W, C, batch, -0.5f, cw + o, 1.5f, st))) return rc;   // W = 1.5 I - 0.5 a^2 Z Y
+        if ((rc = small_gemm_nn(Y, W, Y2, C, batch, 1.f, cy + o, 0.f, st))) return rc;     // Y <- a Y W
+        if ((rc = small_gemm_nn(W, Z, Z2, C, batch, 1.f, cz + o, 0.f, st))) return rc;     // Z <- a W Z
         float* t = Y; Y = Y2; Y2 = t;
         t = Z; Z = Z2; Z2 = t;
     }
@@ -307,8 +350,8 @@ extern "C" int optex_chol_inv(const float* A, long a_seg_stride, int C, int batc
 
 extern "C" size_t optex_spd_sqrt_ws_bytes(int C, int batch) { return ns_ws_floats(C, batch) * sizeof(float); }
 
-extern "C" int optex_spd_sqrt(const float* A, long a_seg_stride, int C, int batch, float* Y, float* Z, void* ws, size_t ws_bytes,
-                              void* stream) {
+extern "C" int optex_spd_sqrt(const float* A, long a_seg_stride, int C, int batch, float lambda_min, float* Y, float* Z, void* ws,
+                              size_t ws_bytes, void* stream) {
     if (!A || C < 1 || batch < 1 || a_seg_stride < 0) {
         set_error("optex_spd_sqrt: bad argument (C=%d batch=%d)", C, batch);
         return OPTEX_E_ARG;
@@ -316,7 +359,7 @@ extern "C" int optex_spd_sqrt(const float* A, long a_seg_stride, int C, int batc
     if (int rc = check_ws("optex_spd_sqrt", ws, ws_bytes, optex_spd_sqrt_ws_bytes(C, batch))) return rc;
     hipStream_t st = as_stream(stream);
     float *y, *z;
-    int rc = ns_sqrt(A, a_seg_stride, C, batch, static_cast<float*>(ws), &y, &z, st);
+    int rc = ns_sqrt(A, a_seg_stride, C, batch, lambda_min, static_cast<float*>(ws), &y, &z, st);
     if (rc) return rc;
     if (Y && (rc = dcopy(Y, y, (size_t)batch * C * C, st))) return rc;
     if (Z && (rc = dcopy(Z, z, (size_t)batch * C * C, st))) return rc;
@@ -328,7 +371,7 @@ extern "C" size_t optex_transfer_operator_ws_bytes(int mode, int C, int n_seg, i
 }
 
 extern "C" int optex_transfer_operator(int mode, const float* cov_t, const float* cov_s, int C, int n_seg, int src_n_seg,
-                                       float* Tt, void* ws, size_t ws_bytes, void* stream) {
+                                       float eps, float* Tt, void* ws, size_t ws_bytes, void* stream) {
     if (!cov_t || !cov_s || !Tt || C < 1 || n_seg < 1 || (src_n_seg != 1 && src_n_seg != n_seg) || mode < 2 || mode > 4) {
         set_error("optex_transfer_operator: bad argument (mode=%d C=%d n_seg=%d src_n_seg=%d; modes 2 = chol, 3 = pca, 4 = sym)",
                   mode, C, n_seg, src_n_seg);
@@ -349,19 +392,19 @@ extern "C" int optex_transfer_operator(int mode, const float* cov_t, const float
     }
     float *Y, *Z;
     if (mode == 3) {  // histmatch.py:29-34
-        if ((rc = ns_sqrt(cov_s, (long)cc, C, Ss, w.ns_buf, &Y, &Z, st))) return rc;
+        if ((rc = ns_sqrt(cov_s, (long)cc, C, Ss, eps, w.ns_buf, &Y, &Z, st))) return rc;
         if ((rc = dcopy(w.Ys, Y, Ss * cc, st))) return rc;
-        if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+        if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, eps, w.ns_buf, &Y, &Z, st))) return rc;
         return small_gemm(Z, C, (long)cc, w.Ys, C, Ss > 1 ? (long)cc : 0, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
     }
     // histmatch.py:36-42
-    if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+    if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, eps, w.ns_buf, &Y, &Z, st))) return rc;
     if ((rc = dcopy(w.Yt, Y, n_seg * cc, st))) return rc;
     if ((rc = dcopy(w.Zt, Z, n_seg * cc, st))) return rc;
     if ((rc = small_gemm(cov_s, C, Ss > 1 ? (long)cc : 0, w.Yt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
         return rc;
     if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, true))) return rc;
-    if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+    if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, eps * eps, w.ns_buf, &Y, &Z, st))) return rc;
     if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false))) return rc;
     return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, Tt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
 }

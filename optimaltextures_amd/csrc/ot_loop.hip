@@ -20,7 +20,7 @@ __global__ void rot_mean_kernel(const float* __restrict__ R, const float* __rest
 int chol_np(int C);
 int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st);
 size_t ns_ws_floats(int C, int batch);
-int ns_sqrt(const float* A, long a_ss, int C, int batch, float* buf, float** Yout, float** Zout, hipStream_t st);
+int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float* buf, float** Yout, float** Zout, hipStream_t st);
 }  // namespace optex
 
 namespace {
@@ -148,7 +148,7 @@ int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg
                           0.f, st, false);
     }
     float *Y, *Z;
-    if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;
+    if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, kEps, w.ns_buf, &Y, &Z, st))) return rc;
     if (mode == MODE_PCA) {
         // histmatch.py:29-34  T = Q_s Q_t^-1  ->  T^T = Q_t^-1 Q_s   (both symmetric)
         const float* Ys = w.Ys + (size_t)it * Ss * cc;
@@ -162,7 +162,7 @@ int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg
         return rc;                                                                    // S_s Q_t
     if ((rc = small_gemm(w.Yt, C, (long)cc, w.G1, C, (long)cc, w.G, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, true)))
         return rc;                                                                    // Q_t S_s Q_t
-    if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, w.ns_buf, &Y, &Z, st))) return rc;     // its square root
+    if ((rc = ns_sqrt(w.G, (long)cc, C, n_seg, kEps * kEps, w.ns_buf, &Y, &Z, st))) return rc;     // its square root
     if ((rc = small_gemm(Y, C, (long)cc, w.Zt, C, (long)cc, w.G1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
         return rc;                                                                    // (.)^1/2 Q_t^-1
     return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
@@ -190,7 +190,7 @@ int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int 
     if (mode == MODE_CHOL) return launch_chol_inv(w.cov_sr, (long)cc, C, iters * Ss, w.Us, w.Ls, st);
     if (mode == MODE_PCA) {
         float *Y, *Z;
-        if ((rc = ns_sqrt(w.cov_sr, (long)cc, C, iters * Ss, w.ns_buf, &Y, &Z, st))) return rc;
+        if ((rc = ns_sqrt(w.cov_sr, (long)cc, C, iters * Ss, kEps, w.ns_buf, &Y, &Z, st))) return rc;
         return copy_async(w.Ys, Y, (size_t)iters * Ss * cc, st);
     }
     return OPTEX_OK;

@@ -31,14 +31,14 @@ def _spd_sqrt_pair(cov: Tensor):
     return (v * r.unsqueeze(-2)) @ v.mT, (v / r.unsqueeze(-2)) @ v.mT
 
 
-def transfer_operator(cov_t: Tensor, cov_s: Tensor, mode: str) -> Tensor:
+def transfer_operator(cov_t: Tensor, cov_s: Tensor, mode: str, eps: float = 1.0) -> Tensor:
     """T with matched = T @ hist_t (histmatch.py:24-42); cov_* are [..., C, C] (batched over independent segments)."""
     if mode not in LINEAR_MODES:
         raise ValueError(f"unknown linear mode {mode!r}")
     c = cov_t.shape[-1]
     if c <= ops.LINEAR_MAX_C:
         ct, cs = cov_t.reshape(-1, c, c), cov_s.reshape(-1, c, c)
-        return ops.transfer_operator_t(ct, cs, mode).mT.reshape(cov_t.shape)
+        return ops.transfer_operator_t(ct, cs, mode, eps).mT.reshape(cov_t.shape)
     return _transfer_operator_torch(cov_t, cov_s, mode)
 
 
@@ -68,7 +68,7 @@ def linear_match_pooled(t_cm: Tensor, bt: int, s_cm: Tensor, bs: int, mode: str,
     if bs != bt and bs != 1 and bt != 1:
         raise RuntimeError(f"The size of tensor a ({bt}) must match the size of tensor b ({bs}) at non-singleton dimension 1")
     if c <= ops.LINEAR_MAX_C:  # At[k][m] = T[m][k], straight from the device factorization
-        Tt = ops.transfer_operator_t(cov_t[None], cov_s[None], mode)[0]
+        Tt = ops.transfer_operator_t(cov_t[None], cov_s[None], mode, eps)[0]
     else:
         Tt = _transfer_operator_torch(cov_t, cov_s, mode).mT.contiguous()
     out = torch.empty_like(t_cm)

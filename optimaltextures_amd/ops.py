@@ -157,19 +157,20 @@ def chol_inv(a):
     return u[:, :c, :c], li[:, :c, :c]
 
 
-def spd_sqrt(a):
+def spd_sqrt(a, lambda_min=0.0):
     """a [B, C, C] symmetric positive definite -> (a^1/2, a^-1/2): the reference's eve @ sqrt(diag(eva)) @ eve.T
-    (histmatch.py:30-31) and its inverse, by Newton-Schulz iterations on the MFMA GEMM"""
+    (histmatch.py:30-31) and its inverse, by scaled Newton-Schulz iterations on the MFMA GEMM; lambda_min = a lower
+    bound of the spectrum when one is known (the eps of cov + eps * I)"""
     lib = _lib.lib()
     a = _f32c(a).contiguous()
     b, c, _ = a.shape
     y, z = torch.empty_like(a), torch.empty_like(a)
     ws = workspace(lib.optex_spd_sqrt_ws_bytes(c, b), a.device)
-    check(lib.optex_spd_sqrt(ptr(a), c * c, c, b, ptr(y), ptr(z), ptr(ws), ws.numel(), stream_ptr()))
+    check(lib.optex_spd_sqrt(ptr(a), c * c, c, b, float(lambda_min), ptr(y), ptr(z), ptr(ws), ws.numel(), stream_ptr()))
     return y, z
 
 
-def transfer_operator_t(cov_t, cov_s, mode):
+def transfer_operator_t(cov_t, cov_s, mode, eps=1.0):
     """T^T per segment (the `At` operand of the apply GEMM): cov_t [S, C, C], cov_s [1 or S, C, C], eps * I included
     (histmatch.py:24-42)"""
     lib = _lib.lib()
@@ -179,7 +180,7 @@ def transfer_operator_t(cov_t, cov_s, mode):
     m = LOOP_MODES[mode]
     out = torch.empty_like(cov_t)
     ws = workspace(lib.optex_transfer_operator_ws_bytes(m, c, s, ss), cov_t.device)
-    check(lib.optex_transfer_operator(m, ptr(cov_t), ptr(cov_s), c, s, ss, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+    check(lib.optex_transfer_operator(m, ptr(cov_t), ptr(cov_s), c, s, ss, float(eps), ptr(out), ptr(ws), ws.numel(), stream_ptr()))
     return out
 
 
