@@ -75,10 +75,11 @@ def main():
                 if c in mean:
                     d.append(f"{c} / SQ_WAVE_CYCLES = {mean[c] / wc:.3f}")
         if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
-            d.append(f"MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = "
-                     f"**{mean['SQ_VALU_MFMA_BUSY_CYCLES'] / (mean['GRBM_GUI_ACTIVE'] * 1024):.3f}**")
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (one GRBM each): / 8 = shader cycles of the dispatch
+            d.append(f"MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = "
+                     f"**{mean['SQ_VALU_MFMA_BUSY_CYCLES'] / (mean['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}**")
         if "GRBM_GUI_ACTIVE" in mean and durs[k]:
-            d.append(f"effective shader clock = GRBM_GUI_ACTIVE / duration = {mean['GRBM_GUI_ACTIVE'] / (sum(durs[k]) / len(durs[k])) / 1e3:.2f} GHz")
+            d.append(f"effective shader clock = GRBM_GUI_ACTIVE / 8 XCDs / duration = {mean['GRBM_GUI_ACTIVE'] / 8 / (sum(durs[k]) / len(durs[k])) / 1e3:.2f} GHz")
         lines += [f"* {x}" for x in d] + [""]
     open(args.out, "w").write("\n".join(lines))
     print("\n".join(lines))
