@@ -516,7 +516,7 @@ static int sort_path_override() {
         const char* e = getenv("OPTEX_SORT_PATH");
         if (!e) return 0;
         if (e[0] == 'r' && e[1] == 'a' && e[2] == 'd') return 1;
-        if (e[0] == 'r' && e[1] == 'a' && e[2] == 'n') return (e[3] == 'k' && e[4] == '2') ? 3 : 2;
+        if (e[0] == 'r' && e[1] == 'a' && e[2] == 'n' && e[3] == 'k') return e[4] == '1' ? 2 : (e[4] == '2' ? 3 : 0);
         return 0;
     }();
     return v;

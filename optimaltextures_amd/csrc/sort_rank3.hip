@@ -34,24 +34,27 @@ constexpr uint32_t R3_LONG = 0x8000u;      // start entry: bucket does not fit t
 constexpr uint32_t R3_BIGF = 0x4000u;      // start entry: bucket larger than RK_BIG
 constexpr uint32_t R3_SMASK = 0x3fffu;     // start entry: first slot of the bucket (mod 16384)
 constexpr int R3_WIN = 8;
+constexpr int R3_QWIN = 52;                // window of a queued key, slots: covers (start & 3) + RK_BIG
 constexpr int R3_BBITS = 13;               // bucket id bits in the owner's (b, a) register
 
 template <int ITEMS>
 struct R3 {
     static constexpr int CAP = ITEMS * SORT_NT;
     // buckets + 1 spare per coarse bin; 16 keys per thread: what fits 80 KiB next to the 64 KiB of slots
-    static constexpr int NBT = ITEMS == 16 ? 7936 : (CAP < 8192 ? CAP : 8192);
+    static constexpr int NBT = ITEMS == 16 ? 7872 : (CAP < 8192 ? CAP : 8192);
     static constexpr int NB = NBT - RK_COARSE;
     static constexpr int NW2 = NBT / 2;                               // packed u16 counters -> start entries
     static constexpr int PER = (NW2 + SORT_NT - 1) / SORT_NT;
     static constexpr int NWORDS = CAP / 32;
-    static constexpr int QCAP = NW2 / 4;                              // key, meta, pixel, result per queue entry
-    static constexpr int SLOTW = CAP + R3_WIN + 4;                    // + window padding behind the last key + a dummy slot
+    static constexpr int TCAP = 256;                                  // queue entries with an equal partner
+    static constexpr int QCAP = (NW2 - TCAP) / 4;                     // key, window, pixel, result per queue entry
+    static constexpr int SLOTW = CAP + R3_QWIN + 4;                   // + window padding behind the last key + a dummy slot
     static constexpr int CNTW = NW2 + 4;                              // + the entry behind the last bucket
     static constexpr size_t LDS = (size_t)(SLOTW + CNTW + 32 + 32) * 4;
     static_assert(NBT <= (1 << R3_BBITS), "bucket id must fit its bit field");
     static_assert(2 * NWORDS <= NW2, "big-bucket scratch aliases the counters");
     static_assert(NBT % 2 == 0 && RK_COARSE <= CAP, "layout");
+    static_assert(R3_QWIN % 4 == 0 && R3_QWIN >= 3 + RK_BIG, "a queued key's window must cover its bucket");
 };
 
 // acc += (a < b), acc += (a <= b): compare + add-with-carry, two instructions each
@@ -88,18 +91,19 @@ __device__ __forceinline__ void r3_window(uint32_t& lt, uint32_t& le, const uint
 template <int ITEMS, bool VEC>
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match3_kernel(SortArgs a) {
     using K = R3<ITEMS>;
-    constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, QCAP = K::QCAP;
+    constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, QCAP = K::QCAP, TCAP = K::TCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* slot = reinterpret_cast<uint32_t*>(smem);   // [CAP + 8 + 4] keys by bucket position; later the sorted source column
+    uint32_t* slot = reinterpret_cast<uint32_t*>(smem);   // [CAP + 52 + 4] keys by bucket position; later the sorted source column
     uint32_t* cnt = slot + K::SLOTW;                      // [NW2 + 4] packed u16 bucket counts -> start entries
     uint32_t* red = cnt + K::CNTW;                        // [32]
     uint32_t* misc = red + 32;                            // [32] nbig, noteq, (start, count) x RK_MAXBIG, [20] queue length
     uint32_t* c1 = slot;                                  // [256] coarse histogram, then base | width << 16 (dead before the slots fill)
     const unsigned short* st16 = reinterpret_cast<const unsigned short*>(cnt);
     uint32_t* qkey = cnt;                                 // queue (the start entries are dead by then)
-    uint32_t* qmeta = cnt + QCAP;
+    uint32_t* qwin = cnt + QCAP;
     uint32_t* qpix = cnt + 2 * QCAP;
     uint32_t* qres = cnt + 3 * QCAP;
+    uint32_t* tlist = cnt + 4 * QCAP;                     // [TCAP] queue entries whose key has an equal partner
     uint32_t* bitmap = cnt;                               // [NWORDS] big-bucket pass
     uint32_t* bpre = cnt + NWORDS;                        // [NWORDS]
 
@@ -141,19 +145,17 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     for (int i = tid; i < K::CNTW; i += SORT_NT) cnt[i] = 0u;
     if (tid < RK_COARSE) c1[tid] = 0u;
     if (tid < 32) misc[tid] = 0u;
-    if (tid >= SORT_NT - R3_WIN) slot[n + (tid - (SORT_NT - R3_WIN))] = 0xffffffffu;  // larger than every finite key
+    if (tid >= SORT_NT - R3_QWIN) slot[n + (tid - (SORT_NT - R3_QWIN))] = 0xffffffffu;  // larger than every finite key
 
     // ---- 1. min / max
     uint32_t klo = 0xffffffffu, khi = 0u;
-    // (registers past the end of a short column hold a copy of a real key — clamped loads — and stay out of every
-    // LDS update below through selects, not branches: per-register branches make the compiler keep the register arrays
-    // as 16-wide tuples and spill them whole)
+    // (registers past the end of a short column hold a copy of a real key — clamped loads: harmless for min / max — and
+    // stay out of every LDS update below through selects, not branches: per-register branches make the compiler keep the
+    // register arrays as 16-wide tuples and spill them whole)
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
-        const bool ok = valid(r);
-        const uint32_t kl = ok ? key[r] : 0xffffffffu, kh = ok ? key[r] : 0u;
-        klo = kl < klo ? kl : klo;
-        khi = kh > khi ? kh : khi;
+        klo = key[r] < klo ? key[r] : klo;
+        khi = key[r] > khi ? key[r] : khi;
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
@@ -240,24 +242,36 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     //         x -> b is monotone non-decreasing whatever the rounding: every step (subtract, scale, truncate, clamp) is.
     //         ba[r] = b | a << 13
     uint32_t ba[ITEMS];
+    constexpr int G4 = ITEMS < 4 ? ITEMS : 4;  // LDS operations of G4 keys in flight together (the wave has no other ILP)
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const float t = (key2f(key[r]) - lo) * s1;
-        int bin = (int)t;
-        bin = bin > RK_COARSE - 1 ? RK_COARSE - 1 : bin;
-        const float frac = t - (float)bin;
-        const uint32_t bw = c1[bin];
-        const int wd = (int)(bw >> 16);
-        const float u = frac * (float)wd;
-        int sub = (int)u;
-        sub = sub > wd - 1 ? wd - 1 : sub;
-        const uint32_t b = (bw & 0xffffu) + (uint32_t)sub;
-        const uint32_t sh = (b & 1u) << 4;
-        const uint32_t old = atomicAdd(&cnt[b >> 1], (valid(r) ? 1u : 0u) << sh);
-        ba[r] = b | (((old >> sh) & 0xffffu) << R3_BBITS);
-        // four returning atomics in flight, then their (b, a) words packed: otherwise the compiler keeps b and the atomic's
-        // result apart until step 6 and spills both (64-VGPR budget)
-        if ((r & 3) == 3) asm volatile("" : "+v"(ba[r - 3]), "+v"(ba[r - 2]), "+v"(ba[r - 1]), "+v"(ba[r]) : : "memory");
+    for (int g = 0; g < ITEMS; g += G4) {
+        float fr[G4];
+        uint32_t bw[G4], bb[G4], old[G4];
+#pragma unroll
+        for (int j = 0; j < G4; j++) {
+            const float t = (key2f(key[g + j]) - lo) * s1;
+            int bin = (int)t;
+            bin = bin > RK_COARSE - 1 ? RK_COARSE - 1 : bin;
+            fr[j] = t - (float)bin;
+            bw[j] = c1[bin];
+        }
+#pragma unroll
+        for (int j = 0; j < G4; j++) {
+            const int wd = (int)(bw[j] >> 16);
+            const float u = fr[j] * (float)wd;
+            int sub = (int)u;
+            sub = sub > wd - 1 ? wd - 1 : sub;
+            bb[j] = (bw[j] & 0xffffu) + (uint32_t)sub;
+        }
+#pragma unroll
+        for (int j = 0; j < G4; j++)
+            old[j] = atomicAdd(&cnt[bb[j] >> 1], (valid(g + j) ? 1u : 0u) << ((bb[j] & 1u) << 4));
+#pragma unroll
+        for (int j = 0; j < G4; j++) ba[g + j] = bb[j] | (((old[j] >> ((bb[j] & 1u) << 4)) & 0xffffu) << R3_BBITS);
+        // the (b, a) words packed here: otherwise the compiler keeps b and the atomic's result apart until step 6 and
+        // spills both (64-VGPR budget)
+        if (G4 == 4) asm volatile("" : "+v"(ba[g]), "+v"(ba[g + 1]), "+v"(ba[g + 2]), "+v"(ba[g + 3]) : : "memory");
+        else asm volatile("" ::: "memory");
     }
     __syncthreads();
     SORT_PROBE(4);
@@ -301,17 +315,19 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         return;
     }
     SORT_PROBE(5);
-    // ---- 6. every key takes its slot start[b] + a.  ba[r] becomes the bucket's start entry (| count << 16 when flagged)
+    // ---- 6. every key takes its slot start[b] + a.  ba[r] becomes the bucket's start entry
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t b = ba[r] & ((1u << R3_BBITS) - 1u), arr = ba[r] >> R3_BBITS;
-        const uint32_t e = st16[b];
-        const uint32_t s = e & R3_SMASK;
-        slot[valid(r) ? s + arr : (uint32_t)(CAP + R3_WIN)] = key[r];
-        // the bucket's size rides along for the buckets the window cannot take (one more read; ~3 % of the keys need it)
-        const uint32_t cb = ((uint32_t)st16[b + 1] - s) & R3_SMASK;
-        ba[r] = e | ((e & R3_LONG) ? cb << 16 : 0u);
-        if ((r & 3) == 3) asm volatile("" ::: "memory");
+    for (int g = 0; g < ITEMS; g += G4) {
+        uint32_t e[G4];
+#pragma unroll
+        for (int j = 0; j < G4; j++) e[j] = st16[ba[g + j] & ((1u << R3_BBITS) - 1u)];
+#pragma unroll
+        for (int j = 0; j < G4; j++) {
+            const uint32_t arr = ba[g + j] >> R3_BBITS;
+            slot[valid(g + j) ? (e[j] & R3_SMASK) + arr : (uint32_t)(CAP + R3_QWIN)] = key[g + j];
+            ba[g + j] = e[j];
+        }
+        asm volatile("" ::: "memory");
     }
     __syncthreads();
     // ---- 6b. oversized buckets only come from exact ties: if all keys of such a bucket are equal its ranks are the
@@ -354,27 +370,36 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     //         rank = W0 + #{slot[W0 .. W0 + 7] < key} for the aligned window W0 = start & ~3 whenever it covers the bucket.
     //         ba[r] becomes the rank (or R3_TAG | queue entry).
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t e = ba[r], k = key[r];
-        const uint32_t w0p = e & (R3_SMASK & ~3u);
-        const uint4* wp = reinterpret_cast<const uint4*>(slot + w0p);
-        const uint4 x0 = wp[0], x1 = wp[1];
-        uint32_t lt = 0u, le = 0u;
-        r3_window(lt, le, x0, x1, k);
-        const bool done = (e & R3_DONE) != 0u, lng = (e & R3_LONG) != 0u;
-        // another slot holds the same key: the pixels decide, in the queue
-        const bool queued = valid(r) && !done && (lng || le - lt > 1u);
-        uint32_t qi = 0u;
-        if (queued) {
-            qi = atomicAdd(&misc[20], 1u);
-            if (qi < (uint32_t)QCAP) {
-                qkey[qi] = k;
-                qmeta[qi] = lng ? ((e & R3_SMASK) | ((e >> 16) << 14)) : (w0p | ((uint32_t)R3_WIN << 14));
-                qpix[qi] = (uint32_t)elem(r);
-            }
+    for (int g = 0; g < ITEMS; g += 2) {
+        uint4 x0[2], x1[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint4* wp = reinterpret_cast<const uint4*>(slot + (ba[g + j] & (R3_SMASK & ~3u)));
+            x0[j] = wp[0];
+            x1[j] = wp[1];
         }
-        ba[r] = queued ? (R3_TAG | qi) : (done ? (e & R3_SMASK) : w0p + lt);
-        if (r & 1) asm volatile("" ::: "memory");  // two windows in flight: keeps the unrolled loop inside the 64-VGPR budget
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int r = g + j;
+            const uint32_t e = ba[r], k = key[r];
+            const uint32_t w0p = e & (R3_SMASK & ~3u);
+            uint32_t lt = 0u, le = 0u;
+            r3_window(lt, le, x0[j], x1[j], k);
+            const bool done = (e & R3_DONE) != 0u;
+            // a bucket wider than the window, or another slot with the same key (the pixels decide): the queue
+            const bool queued = valid(r) && !done && ((e & R3_LONG) != 0u || le - lt > 1u);
+            uint32_t qi = 0u;
+            if (queued) {
+                qi = atomicAdd(&misc[20], 1u);
+                if (qi < (uint32_t)QCAP) {
+                    qkey[qi] = k;
+                    qwin[qi] = w0p;
+                    qpix[qi] = (uint32_t)elem(r);
+                }
+            }
+            ba[r] = queued ? (R3_TAG | qi) : (done ? (e & R3_SMASK) : w0p + lt);
+        }
+        asm volatile("" ::: "memory");  // two windows in flight: keeps the unrolled loop inside the 64-VGPR budget
     }
     asm volatile("" ::: "memory");
     SORT_PROBE(7);
@@ -389,8 +414,9 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
             sv[q] = *reinterpret_cast<const float4*>(ssrt + (e0 < ns ? e0 : 0u));
         }
     }
-    // ---- 8. queued keys, one per thread: buckets wider than the window and keys with an equal partner.  Equal keys are
-    //         all in the queue (each of them saw the other): their order is the order of their pixels.
+    // ---- 8. queued keys, one per thread, against a 52-slot window (a bucket has at most RK_BIG keys here): buckets wider
+    //         than the 8-slot window and keys with an equal partner.  Equal keys are all in the queue (each of them saw the
+    //         other): their order is the order of their pixels, settled among the (few) entries of the tie list.
     __syncthreads();
     const uint32_t qn = misc[20];
     if (qn > (uint32_t)QCAP) {  // tie-heavy column: radix kernel
@@ -398,19 +424,36 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         return;
     }
     for (uint32_t i = tid; i < qn; i += SORT_NT) {
-        const uint32_t k = qkey[i], m = qmeta[i];
-        const uint32_t s = m & R3_SMASK, cb = m >> 14;
+        const uint32_t k = qkey[i], w0p = qwin[i];
+        const uint4* wp = reinterpret_cast<const uint4*>(slot + w0p);
         uint32_t lt = 0u, le = 0u;
-        for (uint32_t j = 0; j < cb; j++) {
-            const uint32_t kj = slot[s + j];
-            r3_add_lt(lt, kj, k);
-            r3_add_le(le, kj, k);
+#pragma unroll 1
+        for (int j = 0; j < R3_QWIN / 8; j++) r3_window(lt, le, wp[2 * j], wp[2 * j + 1], k);
+        if (R3_QWIN % 8) {
+            const uint4 x = wp[R3_QWIN / 4 - 1];
+            r3_add_lt(lt, x.x, k); r3_add_lt(lt, x.y, k); r3_add_lt(lt, x.z, k); r3_add_lt(lt, x.w, k);
+            r3_add_le(le, x.x, k); r3_add_le(le, x.y, k); r3_add_le(le, x.z, k); r3_add_le(le, x.w, k);
         }
-        if (le - lt > 1u) {
-            const uint32_t pix = qpix[i];
-            for (uint32_t j = 0; j < qn; j++) lt += (qkey[j] == k && qpix[j] < pix) ? 1u : 0u;
+        qres[i] = w0p + lt;
+        if (le - lt > 1u) {  // a handful per column (exactly equal fp32 keys): compacted, so that nobody scans the whole queue
+            const uint32_t t = atomicAdd(&misc[21], 1u);
+            if (t < (uint32_t)TCAP) tlist[t] = i;
         }
-        qres[i] = s + lt;
+    }
+    __syncthreads();
+    const uint32_t tn = misc[21];
+    if (tn > (uint32_t)TCAP) {  // tie-heavy column: radix kernel
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    for (uint32_t t = tid; t < tn; t += SORT_NT) {
+        const uint32_t i = tlist[t], k = qkey[i], pix = qpix[i];
+        uint32_t before = 0u;
+        for (uint32_t u = 0; u < tn; u++) {
+            const uint32_t j = tlist[u];
+            before += (qkey[j] == k && qpix[j] < pix) ? 1u : 0u;
+        }
+        qres[i] += before;  // only this thread touches qres[i]
     }
     __syncthreads();
     SORT_PROBE(8);

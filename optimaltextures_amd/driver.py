@@ -300,7 +300,10 @@ class OptimalTexture(torch.nn.Module):
                 content_features.append(cf.contiguous())
         return pastiche, style_features, style_eigvs, content_features, style_hw
 
-    def forward(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor] = None, verbose: bool = False):
+    def forward(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor] = None, verbose: bool = False,
+                on_layer=None):
+        """optex.py:81-139.  on_layer (extension): callable(pass, layer_position, image) invoked after every decoder; a
+        tensor it returns replaces the image (progress previews; teacher-forced parity tests against recorded references)."""
         # multi-GPU: all style broadcasts of this call up front (see prefetch_style_sides); single GPU: pass by pass
         sides = self.prefetch_style_sides(pastiche.shape[-2:], styles, content) if self.style_sync is not None else None
         for p in range(self.passes):
@@ -339,6 +342,10 @@ class OptimalTexture(torch.nn.Module):
                 if self.use_pca:
                     x = unproject_cm(x, style_eigvs[li].t().contiguous())
                 pastiche = decoder.decode(x.view(b, -1, h, w))
+                if on_layer is not None:
+                    replaced = on_layer(p, li, pastiche)
+                    if replaced is not None:
+                        pastiche = replaced
 
         if self.color_transfer is not None:
             assert content is not None, "Color transfer requires content image"
