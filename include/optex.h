@@ -161,8 +161,12 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
  * mode: 0 = cdf, 1 = sort, 2 = chol, 3 = pca, 4 = sym (histmatch.py:5 `mode`; eps = 1 as every caller leaves it).
  *   The linear modes (2-4) take the style's mean and covariance ONCE per call and rotate them as C x C matrices
  *   (cov(S R) = R^T cov(S) R — the style-feature statistics the multi-GPU path broadcasts); the pastiche side is the
- *   literal sequence: rotate, centre, covariance, transfer operator (K5), apply, rotate back.  C <= 512.
- * fuse_rotations = 0: the literal sequence above (three feature-map GEMMs per iteration, like the reference).
+ *   reference's sequence: rotate, centre, covariance of the rotated map, transfer operator (K5), apply, rotate back.
+ *   C <= 512.
+ * fuse_rotations = 0, the default: cdf / sort run the literal sequence (two feature-map GEMMs per iteration); the linear
+ *   modes evaluate their last two products `(T @ hist_t + mu_s) @ R^T` as ONE feature-map GEMM with the C x C matrix
+ *   R T (two feature-map GEMMs per iteration instead of three; same map, fp32 round-off differences).
+ * fuse_rotations = 2: linear modes with the three feature-map GEMMs kept apart (tests, comparisons); cdf / sort: as 0.
  * fuse_rotations = 1, optional fast paths, never the default, results agree to fp32 round-off per step:
  *   cdf / sort (content must be NULL): `(m @ R_i^T) @ R_{i+1}` is evaluated as `m @ (R_i^T R_{i+1})` — one feature-map
  *     GEMM per iteration instead of two;

@@ -192,13 +192,13 @@ constexpr int NS_MAX_ITERS = 64;
 
 // A @ B for `batch` C x C row-major matrices on the MFMA kernel of gemm.hip, which evaluates At^T @ Bm:
 // (A B)^T = B^T A^T, so At := B, Bm := A read "pixel-major" (element (k, i) at i * ld + k) and the result stored
-// pixel-major (transposed back).  OUT = alpha * alpha_seg[b] * (A B) + diag * I.
-int small_gemm_nn(const float* A, const float* B, float* O, int C, int batch, float alpha, const float* alpha_seg, float diag,
-                  hipStream_t st) {
+// pixel-major (transposed back).  OUT = alpha * alpha_seg[b] * (A B) + diag * I.  a_ss / b_ss: matrix strides (0 = shared).
+int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O, int C, int batch, float alpha,
+                  const float* alpha_seg, float diag, hipStream_t st) {
     const long cc = (long)C * C;
     GemmArgs a;
-    a.At = B; a.lda = C; a.at_ss = cc;
-    a.B = A; a.ldb = C; a.b_ss = cc;
+    a.At = B; a.lda = C; a.at_ss = b_ss;
+    a.B = A; a.ldb = C; a.b_ss = a_ss;
     a.O = O; a.ldo = C; a.o_ss = cc;
     a.M = C; a.K = C; a.n = C; a.n_seg = batch;
     a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
@@ -289,9 +289,9 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float
     if (rc) return rc;
     for (int k = 0; k < K; k++) {
         const size_t o = (size_t)k * batch;
-        if ((rc = small_gemm_nn(Z, Y, W, C, batch, -0.5f, cw + o, 1.5f, st))) return rc;   // W = 1.5 I - 0.5 a^2 Z Y
-        if ((rc = small_gemm_nn(Y, W, Y2, C, batch, 1.f, cy + o, 0.f, st))) return rc;     // Y <- a Y W
-        if ((rc = small_gemm_nn(W, Z, Z2, C, batch, 1.f, cz + o, 0.f, st))) return rc;     // Z <- a W Z
+        if ((rc = small_gemm_nn(Z, (long)cc, Y, (long)cc, W, C, batch, -0.5f, cw + o, 1.5f, st))) return rc;   // W = 1.5 I - 0.5 a^2 Z Y
+        if ((rc = small_gemm_nn(Y, (long)cc, W, (long)cc, Y2, C, batch, 1.f, cy + o, 0.f, st))) return rc;     // Y <- a Y W
+        if ((rc = small_gemm_nn(W, (long)cc, Z, (long)cc, Z2, C, batch, 1.f, cz + o, 0.f, st))) return rc;     // Z <- a W Z
         float* t = Y; Y = Y2; Y2 = t;
         t = Z; Z = Z2; Z2 = t;
     }

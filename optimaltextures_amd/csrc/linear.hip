@@ -11,7 +11,8 @@ namespace optex {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int GT = 64;        // Gram output tile (GT x GT), 4 waves as 2 x 2 of one 32x32 MFMA tile each
+constexpr int GT = 64;        // small Gram output tile (GT x GT), 4 waves as 2 x 2 of one 32x32 MFMA tile each (C <= 64)
+constexpr int GT2 = 128;      // large tile: 4 waves as 2 x 2 of 64 x 64 (2 x 2 MFMA tiles): one LDS read per MFMA instead of two
 constexpr int GK = 32;        // pixels staged per chunk
 constexpr int GSTR = GK + 1;  // odd LDS row stride: conflict-free column reads
 constexpr int G_MAX_SPLITS = 64;
@@ -129,13 +130,130 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ x, 
     }
 }
 
+// The same on 128 x 128 output tiles (C > 64): every wave owns a 64 x 64 block = 2 x 2 MFMA tiles, so an LDS fragment
+// feeds two MFMAs instead of one, and a 256-channel map is covered by 3 tile pairs that read 768 rows from L2 instead of
+// 10 pairs reading 1280.  On a diagonal pair the wave below the diagonal (wi = 1, wj = 0) would only recompute the mirror
+// image of its neighbour: it stores nothing and skips its MFMAs.  Dynamic LDS: 2 x 2 x 128 x 33 floats = 66 KiB.
+__global__ __launch_bounds__(256) void gram128_kernel(const float* __restrict__ x, long ld, long seg_stride, long n, int C,
+                                                      const float* __restrict__ mu, long chunk, int tiles,
+                                                      float* __restrict__ part, int vec) {
+    extern __shared__ __align__(16) float g_smem[];
+    float* Xi = g_smem;                       // [2][GT2 * GSTR]
+    float* Xj = g_smem + 2 * GT2 * GSTR;      // [2][GT2 * GSTR]
+    int pi = blockIdx.x, ti = 0;
+    while (pi >= tiles - ti) {
+        pi -= tiles - ti;
+        ti++;
+    }
+    const int tj = ti + pi;
+    const int seg = blockIdx.z, split = blockIdx.y;
+    const float* xs = x + (size_t)seg * seg_stride;
+    const float* mus = mu + (size_t)seg * C;
+    const long p_beg = (long)split * chunk, p_end = (p_beg + chunk < n) ? p_beg + chunk : n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const bool diag = ti == tj;
+    const bool mirror = diag && wi > wj;      // uniform per wave
+
+    constexpr int NQ = GT2 * GK / 4 / 256;    // float4 per operand per thread and chunk
+    float4 ri[NQ], rj[NQ];
+    auto load_global = [&](long p0) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int idx = tid + q * 256;
+            const int row = idx / (GK / 4), px = (idx % (GK / 4)) * 4;
+            const long pp = p0 + px;
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                if (which && diag) continue;  // a diagonal pair stages one operand and reads it twice
+                const int ch = (which ? tj : ti) * GT2 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ch < C) {
+                    const float* p = xs + (size_t)ch * ld + pp;
+                    const float m = mus[ch];
+                    if (vec && pp + 3 < p_end) {
+                        v = *reinterpret_cast<const float4*>(p);
+                        v.x -= m; v.y -= m; v.z -= m; v.w -= m;
+                    } else {
+                        if (pp + 0 < p_end) v.x = p[0] - m;
+                        if (pp + 1 < p_end) v.y = p[1] - m;
+                        if (pp + 2 < p_end) v.z = p[2] - m;
+                        if (pp + 3 < p_end) v.w = p[3] - m;
+                    }
+                }
+                if (which) rj[q] = v; else ri[q] = v;
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int idx = tid + q * 256;
+            const int row = idx / (GK / 4), px = (idx % (GK / 4)) * 4;
+            float* di = &Xi[buf * GT2 * GSTR + row * GSTR + px];
+            di[0] = ri[q].x; di[1] = ri[q].y; di[2] = ri[q].z; di[3] = ri[q].w;
+            if (!diag) {
+                float* dj = &Xj[buf * GT2 * GSTR + row * GSTR + px];
+                dj[0] = rj[q].x; dj[1] = rj[q].y; dj[2] = rj[q].z; dj[3] = rj[q].w;
+            }
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    const long nchunks = (p_end - p_beg + GK - 1) / GK;
+    if (nchunks > 0) {
+        load_global(p_beg);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (long kc = 0; kc < nchunks; kc++) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_global(p_beg + (kc + 1) * GK);
+        if (!mirror) {
+            const float* ai = &Xi[buf * GT2 * GSTR + (wi * 64 + l31) * GSTR];
+            const float* bj = &(diag ? Xi : Xj)[buf * GT2 * GSTR + (wj * 64 + l31) * GSTR];
+#pragma unroll
+            for (int j = 0; j < GK / 2; j++) {
+                const float a0 = ai[2 * j + h], a1 = ai[32 * GSTR + 2 * j + h];
+                const float b0 = bj[2 * j + h], b1 = bj[32 * GSTR + 2 * j + h];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nchunks) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+    if (mirror) return;
+    float* o = part + ((size_t)seg * gridDim.y + split) * C * C;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = ti * GT2 + wi * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int j = tj * GT2 + wj * 64 + b * 32 + l31;
+                if (i < C && j < C) o[(size_t)i * C + j] = acc[a][b][r];
+            }
+}
+
 // cov[s][i][j] = sum_split part / N + eps * (i == j); lower triangle mirrored from the upper tiles.
 // pool: one covariance over all segments (the reference's batch semantics), N = n * n_seg.
 __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n_seg, int splits, int pool, float N,
                                     float eps, float* __restrict__ cov) {
     const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.z;
     if (j >= C) return;
-    // element (i, j) lives in tile (i/GT, j/GT) if that is an upper tile, else read (j, i)
+    // element (i, j) lives in the 64 x 64 block (i/64, j/64) if that is an upper block, else read (j, i).  Both Gram kernels
+    // leave exactly the upper 64-blocks behind (the 128-tile kernel skips the block below the diagonal of a diagonal tile).
     const bool upper = (i / GT) <= (j / GT);
     const int ri = upper ? i : j, rj = upper ? j : i;
     float sum = 0.f;
@@ -150,8 +268,13 @@ __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n
 int device_cu_count();
 
 static int gram_splits(long n, int C, int n_seg) {
-    const int tiles = (C + GT - 1) / GT, pairs = tiles * (tiles + 1) / 2;
-    long want = (2L * device_cu_count() + (long)pairs * n_seg - 1) / ((long)pairs * n_seg);
+    // 64-tiles: two blocks' worth of work per CU; 128-tiles (two resident blocks per CU, long blocks): about four rounds of
+    // resident blocks, so that the last round's idle CUs cost a few per cent instead of a third
+    const bool big = C > GT;
+    const int gt = big ? GT2 : GT;
+    const int tiles = (C + gt - 1) / gt, pairs = tiles * (tiles + 1) / 2;
+    const long target = (big ? 8L : 2L) * device_cu_count();
+    long want = (target + (long)pairs * n_seg - 1) / ((long)pairs * n_seg);
     long maxs = (n + 1023) / 1024;
     if (want > maxs) want = maxs;
     if (want > G_MAX_SPLITS) want = G_MAX_SPLITS;
@@ -185,16 +308,38 @@ extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long
     }
     int rc = check_launch("col_mean_kernel");
     if (rc) return rc;
-    const int tiles = (C + GT - 1) / GT, pairs = tiles * (tiles + 1) / 2;
+    const bool big = C > GT;
+    const int gt = big ? GT2 : GT;
+    const int tiles = (C + gt - 1) / gt, pairs = tiles * (tiles + 1) / 2;
     const int splits = gram_splits(n, C, n_seg);
     long chunk = (n + splits - 1) / splits;
     chunk = (chunk + GK - 1) / GK * GK;  // chunk starts stay multiples of 4 pixels (float4 loads)
     float* part = static_cast<float*>(ws);
     {
         // upper-triangular tile pairs only: pairs * GT*GT * 2n flop per segment
-        ProfScope prof(KC_GRAM, st, 2.0 * pairs * GT * GT * (double)n * n_seg, 4.0 * (double)n * C * n_seg);
-        hipLaunchKernelGGL(gram_kernel, dim3(pairs, splits, n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, chunk,
-                           tiles, part, vec);
+        // algorithmic flops = the upper-triangular 64 x 64 blocks: b (b + 1) / 2 * 64 * 64 * 2n per segment
+        const int b64 = (C + GT - 1) / GT;
+        ProfScope prof(KC_GRAM, st, 2.0 * (b64 * (b64 + 1) / 2) * GT * GT * (double)n * n_seg, 4.0 * (double)n * C * n_seg);
+        if (big) {
+            const size_t lds = (size_t)4 * GT2 * GSTR * sizeof(float);
+            static bool attr_done[64] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (!attr_done[dev & 63]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram128_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) {
+                    set_error("gram128_kernel: cannot reserve LDS: %s", hipGetErrorString(e));
+                    return OPTEX_E_LAUNCH;
+                }
+                attr_done[dev & 63] = true;
+            }
+            hipLaunchKernelGGL(gram128_kernel, dim3(pairs, splits, n_seg), dim3(256), lds, st, x, ld, seg_stride, n, C, mu,
+                               chunk, tiles, part, vec);
+        } else {
+            hipLaunchKernelGGL(gram_kernel, dim3(pairs, splits, n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, chunk,
+                               tiles, part, vec);
+        }
     }
     if ((rc = check_launch("gram_kernel"))) return rc;
     const float N = pool ? (float)((double)n * n_seg) : (float)n;

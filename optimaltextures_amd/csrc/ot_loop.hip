@@ -7,8 +7,10 @@
 // modes 2 / 3 / 4 (chol, pca, sym — histmatch.py:16-44): the matcher only needs the style's mean and covariance, and
 //   cov(S R) = R^T cov(S) R,  mean(S R) = mean(S) R   (the eps * I term is rotation-invariant),
 // so the style statistics are taken ONCE per call and rotated as C x C matrices for all iterations up front — exactly the
-// "style-feature statistics" the north star broadcasts between GPUs.  The pastiche side is literal: rotate, centre,
-// covariance, transfer operator, apply, rotate back — with the C x C factorizations on the device (linalg.hip).
+// "style-feature statistics" the north star broadcasts between GPUs.  The pastiche side follows the reference step by
+// step — rotate, centre, covariance of the rotated map, transfer operator — with the C x C factorizations on the device
+// (linalg.hip); the last two products, `T @ hist_t` and `@ R^T`, are evaluated as one feature-map GEMM with the C x C
+// matrix R T (fuse_rotations = 2 keeps them apart, 1 is the labelled single-affine fast path).
 #include "gemm_args.h"
 
 using namespace optex;
@@ -16,6 +18,8 @@ using namespace optex;
 namespace optex {
 int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, long b_ss, float* O, long ldo, long o_ss, int C,
                int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st, bool sym);
+int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O, int C, int batch, float alpha,
+                  const float* alpha_seg, float diag, hipStream_t st);
 __global__ void rot_mean_kernel(const float* __restrict__ R, const float* __restrict__ mu, int C, int per, float* __restrict__ out);
 int chol_np(int C);
 int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st);
@@ -79,7 +83,10 @@ struct LoopWs {
         const int NP = chol_np(C);
         const size_t pp = (size_t)NP * NP;
         const size_t nb = NS > (size_t)n_seg ? NS : (size_t)n_seg;
-        if (!fused) {
+        if (fused == 0) {         // default: rotate, then apply + rotate back as one GEMM
+            y = b.take<float>(xs);
+            M1 = b.take<float>((size_t)n_seg * cc);
+        } else if (fused == 2) {  // literal three-GEMM sequence
             y = b.take<float>(xs);
             y2 = b.take<float>(xs);
         } else {
@@ -209,7 +216,22 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
         const float* R = R32 + (size_t)it * cc;
         const float* Rt = Rt32 + (size_t)it * cc;
         const float* mu_sr = w.mu_sr + (size_t)it * Ss * C;
-        if (!fused) {
+        if (fused == 0) {
+            // optex.py:170  rotated_pastiche = pastiche_feature @ rotation
+            if ((rc = fgemm(R, 0, x, w.y, C, n, n_seg, nullptr, nullptr, 0, nullptr, 0.f, stream))) return rc;
+            // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I   (statistics of the ROTATED map, like the reference)
+            if ((rc = optex_linear_stats(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes, stream)))
+                return rc;
+            if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, Ss, it, st))) return rc;   // At = T^T
+            // histmatch.py:27/34/42,44 + optex.py:175, 115-117:  (T hist_t + mu_sr) @ R^T  evaluated as ONE feature-map GEMM
+            //   x = (R T)(y - mu_t) + R mu_sr,   R mu_sr = R R^T mu_s = mu_s,   (R T)^T = T^T R^T = At @ Rt
+            // — the same product in another association (a C x C GEMM instead of a second C x n one); the content blend
+            // rides in the epilogue as before.
+            if ((rc = small_gemm_nn(w.At, (long)cc, Rt, 0, w.M1, C, n_seg, 1.f, nullptr, 0.f, st))) return rc;
+            if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream)))
+                return rc;
+        } else if (fused == 2) {
+            // the literal sequence, three feature-map GEMMs (kept for tests and comparisons)
             // optex.py:170  rotated_pastiche = pastiche_feature @ rotation
             if ((rc = fgemm(R, 0, x, w.y, C, n, n_seg, nullptr, nullptr, 0, nullptr, 0.f, stream))) return rc;
             // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I
@@ -241,7 +263,7 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
             float* t = cur; cur = nxt; nxt = t;
         }
     }
-    if (fused && cur != x) return copy_async(x, cur, (size_t)n_seg * xs, st);
+    if (fused == 1 && cur != x) return copy_async(x, cur, (size_t)n_seg * xs, st);
     return OPTEX_OK;
 }
 
@@ -251,7 +273,7 @@ extern "C" size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n
                                          int fuse_rotations) {
     LoopWs w;
     Bump b(nullptr);
-    w.layout(b, mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations);
+    w.layout(b, mode, n, ns, C, n_seg, src_n_seg, iters, (mode < MODE_CHOL && fuse_rotations == 2) ? 0 : fuse_rotations);
     return b.off;
 }
 
@@ -271,6 +293,11 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         return OPTEX_E_ARG;
     }
     const bool linear = mode >= MODE_CHOL;
+    if (fuse_rotations < 0 || fuse_rotations > 2) {
+        set_error("optex_ot_loop: fuse_rotations = %d (0, 1 or 2)", fuse_rotations);
+        return OPTEX_E_ARG;
+    }
+    if (!linear && fuse_rotations == 2) fuse_rotations = 0;
     if (fuse_rotations && content && !linear) {
         set_error("optex_ot_loop: fuse_rotations needs the un-rotated pastiche between iterations for the content blend");
         return OPTEX_E_ARG;

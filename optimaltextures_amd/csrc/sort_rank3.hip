@@ -279,13 +279,30 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     {
         uint32_t wv[PER];
         unsigned sum = 0;
+        if (PER == 4) {  // one 16-byte read (the counters start on a 16-byte boundary)
+            const uint4 c4 = tid * 4 < NW2 ? *reinterpret_cast<const uint4*>(cnt + tid * 4) : make_uint4(0u, 0u, 0u, 0u);
+            wv[0] = c4.x; wv[1 % PER] = c4.y; wv[2 % PER] = c4.z; wv[3 % PER] = c4.w;
+        } else {
 #pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const int i = tid * PER + q;
-            wv[q] = i < NW2 ? cnt[i] : 0u;
-            sum += (wv[q] & 0xffffu) + (wv[q] >> 16);
+            for (int q = 0; q < PER; q++) {
+                const int i = tid * PER + q;
+                wv[q] = i < NW2 ? cnt[i] : 0u;
+            }
         }
-        unsigned ex = block_excl_scan(sum, red, nullptr);
+#pragma unroll
+        for (int q = 0; q < PER; q++) sum += (wv[q] & 0xffffu) + (wv[q] >> 16);
+        // block-wide exclusive scan with ONE barrier: `red` is not written again before the barrier behind this step
+        unsigned incl = sum;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const unsigned t = __shfl_up(incl, o2);
+            if (lane >= o2) incl += t;
+        }
+        if (lane == 63) red[w] = incl;
+        __syncthreads();
+        unsigned ex = incl - sum;
+#pragma unroll
+        for (int k = 0; k < SORT_NW; k++) ex += k < w ? red[k] : 0u;
         auto entry = [&](unsigned s, unsigned cb) {
             uint32_t e = s & R3_SMASK;
             if ((s & 3u) + cb > (unsigned)R3_WIN) e |= R3_LONG;
@@ -427,9 +444,16 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const uint32_t k = qkey[i], w0p = qwin[i];
         const uint4* wp = reinterpret_cast<const uint4*>(slot + w0p);
         uint32_t lt = 0u, le = 0u;
+        static_assert(R3_QWIN == 52, "two trips of six 16-byte reads + one");
 #pragma unroll 1
-        for (int j = 0; j < R3_QWIN / 8; j++) r3_window(lt, le, wp[2 * j], wp[2 * j + 1], k);
-        if (R3_QWIN % 8) {
+        for (int j = 0; j < 2; j++) {  // six reads in flight per trip
+            const uint4 x0 = wp[6 * j], x1 = wp[6 * j + 1], x2 = wp[6 * j + 2], x3 = wp[6 * j + 3], x4 = wp[6 * j + 4],
+                        x5 = wp[6 * j + 5];
+            r3_window(lt, le, x0, x1, k);
+            r3_window(lt, le, x2, x3, k);
+            r3_window(lt, le, x4, x5, k);
+        }
+        {
             const uint4 x = wp[R3_QWIN / 4 - 1];
             r3_add_lt(lt, x.x, k); r3_add_lt(lt, x.y, k); r3_add_lt(lt, x.z, k); r3_add_lt(lt, x.w, k);
             r3_add_le(le, x.x, k); r3_add_le(le, x.y, k); r3_add_le(le, x.z, k); r3_add_le(le, x.w, k);

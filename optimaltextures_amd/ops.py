@@ -205,7 +205,7 @@ def rotations_from_normals(normals, N, count, device, want64=False):
 
 def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False):
     """optex.py:112-117, all iterations enqueued by one C call, for every hist_mode; x [S, C, n] (independent segments) is
-    updated IN PLACE.  fuse_rotations (labelled fast paths, fp32 round-off differences only): cdf / sort evaluate
+    updated IN PLACE.  fuse_rotations = True / 1 (labelled fast paths, fp32 round-off differences only): cdf / sort evaluate
     (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (needs content=None); the linear modes run the whole step as one
     affine map in un-rotated space."""
     lib = _lib.lib()
@@ -217,7 +217,8 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
     if content is not None:
         assert content.shape == x.shape and content.is_contiguous()
     m = LOOP_MODES[mode]
-    fuse = int(bool(fuse_rotations) and (content is None or m >= 2))
+    # 0 = default, 1 / True = labelled fast path, 2 = linear modes with the apply and the rotation back as separate GEMMs
+    fuse = int(fuse_rotations) if (content is None or m >= 2) else (0 if int(fuse_rotations) == 1 else int(fuse_rotations))
     ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse), x.device)
     check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), iters,
                             ptr(content), ctypes.c_float(strength), fuse, ptr(ws), ws.numel(), stream_ptr()))
