@@ -100,6 +100,31 @@ __global__ __launch_bounds__(256) void col_minmax_kernel(const float* __restrict
     }
 }
 
+// min / max of every (segment, channel) from the per-tile partials the forward rotation GEMM left behind
+// (GemmArgs::rowstat = 1: part [n_seg][parts][C]), joined with the other distribution's range like col_minmax_kernel
+__global__ __launch_bounds__(256) void minmax_from_parts_kernel(const float* __restrict__ pmn, const float* __restrict__ pmx,
+                                                                int parts, int C, int ncols, const float* __restrict__ omn,
+                                                                const float* __restrict__ omx, int o_n_seg,
+                                                                float* __restrict__ mn, float* __restrict__ mx) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    const int seg = col / C, c = col % C;
+    const float* a = pmn + (size_t)seg * parts * C + c;
+    const float* b = pmx + (size_t)seg * parts * C + c;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int p = 0; p < parts; p++) {
+        lo = fminf(lo, a[(size_t)p * C]);
+        hi = fmaxf(hi, b[(size_t)p * C]);
+    }
+    if (omn) {
+        const int oc = ((o_n_seg == 1) ? 0 : seg) * C + c;
+        lo = fminf(lo, omn[oc]);
+        hi = fmaxf(hi, omx[oc]);
+    }
+    mn[col] = lo;
+    mx[col] = hi;
+}
+
 __global__ void minmax_init_kernel(float* mn, float* mx, int ncols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ncols) {
@@ -399,10 +424,27 @@ struct CdfWs {
 int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
                    hipStream_t st) {
+    return cdf_match_parts_impl(target, ldt, tss, nt, source, lds, sss, ns, src_n_seg, C, n_seg, out, ldo, oss, ws, dbg,
+                                nullptr, nullptr, 0, st);
+}
+
+// tmn_parts / tmx_parts [n_seg][parts][C]: per-tile min / max of the target the producing GEMM already took (or NULL)
+int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
+                         int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
+                         const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st) {
     CdfWs w(ws, C, n_seg);
     int rc;
     if ((rc = launch_minmax(source, lds, sss, ns, C, src_n_seg, nullptr, nullptr, 1, w.smn, w.smx, st))) return rc;
-    if ((rc = launch_minmax(target, ldt, tss, nt, C, n_seg, w.smn, w.smx, src_n_seg, w.lo, w.hi, st))) return rc;
+    if (tmn_parts) {
+        const int ncols = C * n_seg;
+        // reads the partials (parts / n of the map's bytes) instead of the map
+        ProfScope prof(KC_MINMAX, st, 0.0, 8.0 * (double)parts * ncols);
+        hipLaunchKernelGGL(minmax_from_parts_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, tmn_parts, tmx_parts, parts, C,
+                           ncols, w.smn, w.smx, src_n_seg, w.lo, w.hi);
+        if ((rc = check_launch("minmax_from_parts_kernel"))) return rc;
+    } else if ((rc = launch_minmax(target, ldt, tss, nt, C, n_seg, w.smn, w.smx, src_n_seg, w.lo, w.hi, st))) {
+        return rc;
+    }
     if ((rc = launch_hist(target, ldt, tss, nt, C, n_seg, n_seg, w.lo, w.hi, w.ht, st))) return rc;
     if ((rc = launch_hist(source, lds, sss, ns, C, src_n_seg, n_seg, w.lo, w.hi, w.hs, st))) return rc;
     const int ncols = C * n_seg;

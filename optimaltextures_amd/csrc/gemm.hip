@@ -268,7 +268,23 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // EXTRA = true adds the operand centring (bsub), the output bias (badd) and the content blend of the general kernel, with
 // the same arithmetic in the same order (bit-identical to gemm_tn_kernel): the apply GEMM of the linear modes
 // (histmatch.py:27/34/42,44) and the blending inverse rotation of style transfer (optex.py:115-117, 175) take this path too.
-template <int BM, int BN, int BK, int WGM, int WGN, bool EXTRA>
+// ROWSTAT: 0 = off, 1 = per-row min / max, 2 = per-row sum of the outputs (GemmArgs::rowstat), reduced over the wave's pixel
+// columns in registers (4 tiles in-lane, then 16 lanes with DPP butterflies) — ~1.5 % more issue slots than the MFMAs
+// of a 256-deep tile, instead of a separate pass that re-reads the whole rotated map from HBM.
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2)); v = fminf(v, __shfl_xor(v, 4)); v = fminf(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v = v + __shfl_xor(v, 1); v = v + __shfl_xor(v, 2); v = v + __shfl_xor(v, 4); v = v + __shfl_xor(v, 8);
+    return v;
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool EXTRA, int ROWSTAT = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -385,6 +401,37 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
                 }
             }
         }
+    if (ROWSTAT != 0) {
+        // one partial per (pixel tile, wave column): [seg][tn_idx * WGN + wn][m]; the statistics are those of the plain
+        // product (this path is only taken without bias / blend)
+        const size_t pbase = ((size_t)seg * a.tiles_n * WGN + (size_t)tn_idx * WGN + wn) * a.M;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + wm * WM + tm * 16 + 4 * kq + r;
+                if (ROWSTAT == 1) {
+                    float mn = acc[tm][0][r], mx = acc[tm][0][r];
+#pragma unroll
+                    for (int tn = 1; tn < TN; tn++) {
+                        mn = fminf(mn, acc[tm][tn][r]);
+                        mx = fmaxf(mx, acc[tm][tn][r]);
+                    }
+                    mn = row16_min(mn);
+                    mx = row16_max(mx);
+                    if (l15 == 0 && m < a.M) {
+                        a.rs_a[pbase + m] = mn;
+                        a.rs_b[pbase + m] = mx;
+                    }
+                } else {
+                    float sm = acc[tm][0][r];
+#pragma unroll
+                    for (int tn = 1; tn < TN; tn++) sm = sm + acc[tm][tn][r];
+                    sm = row16_sum(sm);
+                    if (l15 == 0 && m < a.M) a.rs_a[pbase + m] = sm;
+                }
+            }
+    }
 }
 
 static int gemm_mfma16_env() {
@@ -420,14 +467,23 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
 // Software-pipelined LDS fragment reads, LDS refill under the MFMAs, BK = 8 / 32, and an LDS-free variant streaming
 // fragments straight from L1/L2 were all tried and measured 72-99 TFLOP/s: at 70 % MFMA utilisation the chip already
 // draws 1350 W of its 1400 W cap (rocm-smi), so the kernel is power-limited, not issue-limited.
+int device_cu_count();
+
+// shapes the hot-loop kernel (gemm16_cm_kernel, 256 x 128 tiles) takes; layouts and alignment are checked by the callers
+static bool hot_shape(const GemmArgs& a, int n_cu) {
+    const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
+    const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
+    return big >= 2LL * n_cu && a.M > 64 && gemm_mfma16_env() && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 && a.M > 128 &&
+           huge >= 2LL * n_cu;
+}
+
 template <bool BPM, bool OPM>
 static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     if (a.sym) return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);  // square tiles: the mirrored store needs BM == BN
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
-        if (!BPM && !OPM && vec && gemm_mfma16_env() && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 && a.M > 128 &&
-            huge >= 2LL * n_cu) {
+        if (!BPM && !OPM && vec && hot_shape(a, n_cu)) {
             a.tiles_m = (a.M + 255) / 256;
             a.tiles_n = (int)(a.n / 128);
             const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
@@ -435,6 +491,10 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
                            4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
             if (a.bsub || a.badd || a.content)
                 hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2, true>), dim3((unsigned)total), dim3(512), 0, st, a);
+            else if (a.rowstat == 1)
+                hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2, false, 1>), dim3((unsigned)total), dim3(512), 0, st, a);
+            else if (a.rowstat == 2)
+                hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2, false, 2>), dim3((unsigned)total), dim3(512), 0, st, a);
             else
                 hipLaunchKernelGGL((gemm16_cm_kernel<256, 128, 16, 4, 2, false>), dim3((unsigned)total), dim3(512), 0, st, a);
             return check_launch("gemm16_cm_kernel");
@@ -446,14 +506,22 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);
 }
 
-int device_cu_count();
-
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static bool operands_vec(const GemmArgs& a) {
+    return aligned16(a.At) && a.lda % 4 == 0 && a.at_ss % 4 == 0 && aligned16(a.B) && a.ldb % 4 == 0 && a.b_ss % 4 == 0;
+}
+
+bool gemm_rowstat_supported(const GemmArgs& a) {
+    return operands_vec(a) && !a.bsub && !a.badd && !a.content && hot_shape(a, device_cu_count());
+}
+
+int gemm_rowstat_parts(long n) { return (int)(n / 128) * 2; }  // pixel tiles of 128 x the block's two wave columns
 
 int gemm_tn_launch(GemmArgs& a, int b_layout, int o_layout, hipStream_t st) {
     const bool bpm = b_layout == OPTEX_PIXEL_MAJOR, opm = o_layout == OPTEX_PIXEL_MAJOR;
     // float4 paths need 16-byte aligned rows on every operand that is accessed with vectors
-    bool vec = aligned16(a.At) && a.lda % 4 == 0 && a.at_ss % 4 == 0 && aligned16(a.B) && a.ldb % 4 == 0 && a.b_ss % 4 == 0;
+    bool vec = operands_vec(a);
     if (opm) vec = vec && aligned16(a.O) && a.ldo % 4 == 0 && a.o_ss % 4 == 0;
     const int n_cu = device_cu_count();
     if (!bpm && !opm) return launch_layout<false, false>(a, vec, n_cu, st);
@@ -490,5 +558,6 @@ extern "C" int optex_gemm_tn(const float* At, long lda, long at_seg_stride, cons
     a.badd = badd; a.badd_ss = badd_seg_stride;
     a.content = content; a.strength = strength;
     a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.sym = 0; a.prof_cls = KC_GEMM;
+    a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
     return gemm_tn_launch(a, b_layout, o_layout, as_stream(stream));
 }

@@ -22,7 +22,17 @@ struct GemmArgs {
     // symmetric (half the flops; what keeps the Newton-Schulz iteration of linalg.hip on its stable branch).
     int epi; float alpha; const float* alpha_seg; float diag; int sym;
     int prof_cls;  // KC_GEMM for the feature-map GEMMs, KC_SMALL_GEMM for the C x C products of linalg.hip
+    // optional per-row statistics of the OUTPUT, taken from the accumulators before they are stored (hot-loop kernel only,
+    // gemm_rowstat_supported): 1 = min and max, 2 = sum of every output row over the block's pixel columns, one partial
+    // per (pixel tile, wave column):  rs_a / rs_b [n_seg][gemm_rowstat_parts][M]  (min / sum in rs_a, max in rs_b).
+    // Saves the separate pass over the rotated map that col_minmax_kernel / col_mean_kernel would make.
+    int rowstat; float* rs_a; float* rs_b;
 };
+
+// the launch of `a` (channel-major in and out) takes the hot-loop kernel, i.e. a.rowstat is honoured
+bool gemm_rowstat_supported(const GemmArgs& a);
+// partials per (segment, row) a rowstat launch writes for n pixels
+int gemm_rowstat_parts(long n);
 
 // internal launcher behind optex_gemm_tn (gemm.hip): `a` fully filled except tiles_*; layouts are OPTEX_*_MAJOR
 int gemm_tn_launch(GemmArgs& a, int b_layout, int o_layout, hipStream_t st);

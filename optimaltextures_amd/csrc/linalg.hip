@@ -34,6 +34,7 @@ int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, 
     a.epi = epi ? 1 : 0; a.alpha = alpha; a.alpha_seg = alpha_seg; a.diag = diag;
     a.sym = sym ? 1 : 0;
     a.prof_cls = KC_SMALL_GEMM;
+    a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
     return gemm_tn_launch(a, OPTEX_CHANNEL_MAJOR, OPTEX_CHANNEL_MAJOR, st);
 }
 
@@ -204,6 +205,7 @@ int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O
     a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
     a.epi = 1; a.alpha = alpha; a.alpha_seg = alpha_seg; a.diag = diag; a.sym = 0;
     a.prof_cls = KC_SMALL_GEMM;
+    a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
     return gemm_tn_launch(a, OPTEX_PIXEL_MAJOR, OPTEX_PIXEL_MAJOR, st);
 }
 

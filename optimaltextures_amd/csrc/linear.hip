@@ -40,6 +40,19 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__
     if (threadIdx.x == 0) mu[col] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n);
 }
 
+// spatial mean of every (segment, channel) from the per-tile row sums the forward rotation GEMM left behind
+// (GemmArgs::rowstat = 2: part [n_seg][parts][C]), summed in double in a fixed order
+__global__ __launch_bounds__(256) void mean_from_parts_kernel(const float* __restrict__ psum, int parts, int C, int ncols, long n,
+                                                              float* __restrict__ mu) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    const int seg = col / C, c = col % C;
+    const float* a = psum + (size_t)seg * parts * C + c;
+    double s = 0.0;
+    for (int p = 0; p < parts; p++) s += (double)a[(size_t)p * C];
+    mu[col] = (float)(s / (double)n);
+}
+
 // grid = (tile pairs, splits, n_seg).  part[seg][split][C][C] receives the (ti, tj) tile of this pixel range.
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ x, long ld, long seg_stride, long n, int C,
                                                    const float* __restrict__ mu, long chunk, int tiles,
@@ -273,7 +286,7 @@ static int gram_splits(long n, int C, int n_seg) {
     const bool big = C > GT;
     const int gt = big ? GT2 : GT;
     const int tiles = (C + gt - 1) / gt, pairs = tiles * (tiles + 1) / 2;
-    const long target = (big ? 8L : 2L) * device_cu_count();
+    const long target = (big ? 6L : 2L) * device_cu_count();
     long want = (target + (long)pairs * n_seg - 1) / ((long)pairs * n_seg);
     long maxs = (n + 1023) / 1024;
     if (want > maxs) want = maxs;
@@ -295,6 +308,12 @@ extern "C" size_t optex_linear_stats_ws_bytes(long n, int C, int n_seg) {
 
 extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool,
                                   float eps, float* mu, float* cov, void* ws, size_t ws_bytes, void* stream) {
+    return optex::linear_stats_parts(x, ld, seg_stride, n, C, n_seg, pool, eps, mu, cov, ws, ws_bytes, nullptr, 0, stream);
+}
+
+// sum_parts [n_seg][parts][C]: per-tile row sums of x the producing GEMM already took (or NULL: col_mean_kernel reads x)
+int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool, float eps, float* mu,
+                              float* cov, void* ws, size_t ws_bytes, const float* sum_parts, int parts, void* stream) {
     if (!x || !mu || !cov || !ws || n <= 0 || C <= 0 || n_seg <= 0 || ld < n) {
         set_error("optex_linear_stats: bad argument (n=%ld C=%d n_seg=%d ld=%ld)", n, C, n_seg, ld);
         return OPTEX_E_ARG;
@@ -302,7 +321,11 @@ extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long
     if (int rc = check_ws("optex_linear_stats", ws, ws_bytes, optex_linear_stats_ws_bytes(n, C, n_seg))) return rc;
     hipStream_t st = as_stream(stream);
     const int vec = aligned16(x) && ld % 4 == 0 && seg_stride % 4 == 0;
-    {
+    if (sum_parts) {
+        ProfScope prof(KC_MEAN, st, 0.0, 4.0 * (double)parts * C * n_seg);
+        hipLaunchKernelGGL(mean_from_parts_kernel, dim3((C * n_seg + 255) / 256), dim3(256), 0, st, sum_parts, parts, C,
+                           C * n_seg, n, mu);
+    } else {
         ProfScope prof(KC_MEAN, st, 0.0, 4.0 * (double)n * C * n_seg);
         hipLaunchKernelGGL(col_mean_kernel, dim3(C * n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, vec);
     }
@@ -344,7 +367,7 @@ extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long
     if ((rc = check_launch("gram_kernel"))) return rc;
     const float N = pool ? (float)((double)n * n_seg) : (float)n;
     ProfScope prof(KC_COVFIN, st, 0.0, 4.0 * (double)C * C * n_seg * (splits + 1));
-    hipLaunchKernelGGL(cov_finalize_kernel, dim3((C + 63) / 64, C, pool ? 1 : n_seg), dim3(64), 0, st, part, C, n_seg,
+    hipLaunchKernelGGL(cov_finalize_kernel, dim3((C + 255) / 256, C, pool ? 1 : n_seg), dim3(256), 0, st, part, C, n_seg,
                        splits, pool, N, eps, cov);
     return check_launch("cov_finalize_kernel");
 }

@@ -72,8 +72,13 @@ struct ProfScope {
 int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
                    hipStream_t st);
+int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
+                         int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
+                         const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st);
 int sort_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                     int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, hipStream_t st);
+int linear_stats_parts(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool, float eps, float* mu,
+                       float* cov, void* ws, size_t ws_bytes, const float* sum_parts, int parts, void* stream);
 int device_cu_count();
 
 }  // namespace optex

@@ -64,12 +64,21 @@ struct LoopWs {
     float* ns_buf = nullptr;
     // fused (single-affine) linear path
     float *M1 = nullptr, *Mt = nullptr, *mu_x = nullptr;
+    // per-tile row statistics of the rotated pastiche, written by the forward rotation GEMM's epilogue (GemmArgs::rowstat)
+    float *rs_a = nullptr, *rs_b = nullptr;
+    int rs_parts = 0;
 
     void layout(Bump& b, int mode, long n, long ns, int C, int n_seg, int Ss, int iters, int fused) {
         const size_t xs = (size_t)n_seg * C * n, cc = (size_t)C * C;
+        rs_parts = (n % 128 == 0) ? gemm_rowstat_parts(n) : 0;
+        const size_t rs_floats = (size_t)n_seg * rs_parts * C;
         if (mode == MODE_CDF || mode == MODE_SORT) {
             y = b.take<float>(xs);
             ys = b.take<float>((size_t)Ss * C * ns);
+            if (mode == MODE_CDF && !fused && rs_parts) {
+                rs_a = b.take<float>(rs_floats);
+                rs_b = b.take<float>(rs_floats);
+            }
             if (fused) {
                 y2 = b.take<float>(xs);
                 P = b.take<float>((size_t)(iters > 1 ? iters - 1 : 1) * cc);
@@ -86,6 +95,7 @@ struct LoopWs {
         if (fused == 0) {         // default: rotate, then apply + rotate back as one GEMM
             y = b.take<float>(xs);
             M1 = b.take<float>((size_t)n_seg * cc);
+            if (rs_parts) rs_a = b.take<float>(rs_floats);
         } else if (fused == 2) {  // literal three-GEMM sequence
             y = b.take<float>(xs);
             y2 = b.take<float>(xs);
@@ -138,6 +148,27 @@ int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, 
     const long xs = (long)C * n;
     return optex_gemm_tn(At, C, at_ss, B, n, xs, OPTEX_CHANNEL_MAJOR, O, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, bsub, C,
                          badd, badd_ss, content, strength, stream);
+}
+
+// optex.py:170  rotated = feature @ rotation  on the loop's layouts, with the per-row statistics of the result taken in the
+// GEMM's epilogue when the launch takes the hot-loop kernel (rowstat 1 = min / max, 2 = sums; *took says whether it did)
+int rotate_with_stats(const float* R, const float* x, float* y, int C, long n, int n_seg, int rowstat, float* rs_a, float* rs_b,
+                      bool* took, hipStream_t st) {
+    GemmArgs a;
+    a.At = R; a.lda = C; a.at_ss = 0;
+    a.B = x; a.ldb = n; a.b_ss = (long)C * n;
+    a.O = y; a.ldo = n; a.o_ss = (long)C * n;
+    a.M = C; a.K = C; a.n = n; a.n_seg = n_seg;
+    a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
+    a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.sym = 0; a.prof_cls = KC_GEMM;
+    a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
+    *took = rowstat != 0 && rs_a != nullptr && gemm_rowstat_supported(a);
+    if (*took) {
+        a.rowstat = rowstat;
+        a.rs_a = rs_a;
+        a.rs_b = rs_b;
+    }
+    return gemm_tn_launch(a, OPTEX_CHANNEL_MAJOR, OPTEX_CHANNEL_MAJOR, st);
 }
 
 // Transfer operator of one iteration, transposed (At[k][m] = T[m][k], what the apply GEMM takes), for every pastiche
@@ -217,10 +248,12 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
         const float* Rt = Rt32 + (size_t)it * cc;
         const float* mu_sr = w.mu_sr + (size_t)it * Ss * C;
         if (fused == 0) {
-            // optex.py:170  rotated_pastiche = pastiche_feature @ rotation
-            if ((rc = fgemm(R, 0, x, w.y, C, n, n_seg, nullptr, nullptr, 0, nullptr, 0.f, stream))) return rc;
+            // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (+ the row sums for the means, in the epilogue)
+            bool sums = false;
+            if ((rc = rotate_with_stats(R, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st))) return rc;
             // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I   (statistics of the ROTATED map, like the reference)
-            if ((rc = optex_linear_stats(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes, stream)))
+            if ((rc = linear_stats_parts(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes,
+                                         sums ? w.rs_a : nullptr, w.rs_parts, stream)))
                 return rc;
             if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, Ss, it, st))) return rc;   // At = T^T
             // histmatch.py:27/34/42,44 + optex.py:175, 115-117:  (T hist_t + mu_sr) @ R^T  evaluated as ONE feature-map GEMM
@@ -361,17 +394,18 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         const float* R = R32 + (size_t)it * C * C;
         const float* Rt = Rt32 + (size_t)it * C * C;
         int rc;
-        // optex.py:170  rotated_pastiche = pastiche_feature @ rotation
-        if ((rc = optex_gemm_tn(R, C, 0, x, n, xs, OPTEX_CHANNEL_MAJOR, w.y, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
-                                nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
-            return rc;
+        // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (cdf: + per-channel min / max in the epilogue, which
+        // saves histmatch.py:52-53 its own pass over the rotated map)
+        bool mm = false;
+        if ((rc = rotate_with_stats(R, x, w.y, C, n, n_seg, mode == MODE_CDF ? 1 : 0, w.rs_a, w.rs_b, &mm, st))) return rc;
         // optex.py:171  rotated_style = style_feature @ rotation
         if ((rc = optex_gemm_tn(R, C, 0, style, ns, ss, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C, C,
                                 ns, src_n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
             return rc;
         // optex.py:173  hist_match(rotated_pastiche, rotated_style), in place
         if (mode == MODE_CDF)
-            rc = cdf_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr, st);
+            rc = cdf_match_parts_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr,
+                                      mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, st);
         else
             rc = sort_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, st);
         if (rc) return rc;

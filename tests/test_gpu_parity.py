@@ -936,3 +936,42 @@ def test_config5_two_style_mixing_runs(dev):
         out = tex.forward(torch.rand(1, 3, 512, 512, device=dev), [a, b])
     assert out.shape == (1, 3, 512, 512) and bool(torch.isfinite(out).all())
     assert 0.0 < float(out.std()) < 1.0
+
+
+# ================================================================================================ GEMM epilogue statistics
+def test_ot_loop_cdf_epilogue_minmax_equals_separate_kernels(dev):
+    """At hot-loop shapes the forward rotation GEMM takes the per-channel min / max of its output in its epilogue
+    (GemmArgs::rowstat) and cdf_match skips its own pass over the rotated map (histmatch.py:52-53): the loop must equal
+    the same steps made of the separate C-ABI calls (rotate, cdf_match with its own min / max kernel, rotate back), bit
+    for bit — min and max do not depend on the order they are taken in."""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    g = torch.Generator(device=dev).manual_seed(11)
+    S, C, n, ns, iters = 32, 256, 2048, 1536, 2          # 16 pixel tiles x 32 segments = 512 blocks: the hot-loop kernel
+    x = torch.randn((S, C, n), device=dev, generator=g).clamp_min_(0) * 2
+    sty = torch.randn((1, C, ns), device=dev, generator=g).clamp_min_(0) * 1.5
+    R32, Rt32 = __import__("optimaltextures_amd.rotation", fromlist=["rotations"]).rotations(C, iters, dev, rng=np.random.RandomState(3))
+    got = x.clone()
+    ops.ot_loop("cdf", got, sty, R32, Rt32)
+    want = x.clone()
+    for it in range(iters):
+        y, ys = ops.rotate_seg(want, R32[it]), ops.rotate_seg(sty, R32[it])
+        m = ops.cdf_match_seg(Seg.of(y), Seg.of(ys))
+        want = ops.unrotate_seg(m, Rt32[it])
+    assert torch.equal(got, want)
+
+
+def test_ot_loop_chol_epilogue_sums_match_separate_mean_kernel(dev):
+    """linear modes at a hot-loop shape: the means come from row sums taken in the rotation GEMM's epilogue (fp32 per tile,
+    double across tiles) instead of col_mean_kernel's double sum over the map; fuse_rotations=2 (literal sequence, separate
+    mean kernel) must agree to fp32 round-off"""
+    from optimaltextures_amd import ops
+    g = torch.Generator(device=dev).manual_seed(12)
+    S, C, n, ns, iters = 32, 256, 2048, 1536, 2
+    x = torch.randn((S, C, n), device=dev, generator=g).clamp_min_(0) * 2
+    sty = torch.randn((1, C, ns), device=dev, generator=g).clamp_min_(0) * 1.5
+    R32, Rt32 = __import__("optimaltextures_amd.rotation", fromlist=["rotations"]).rotations(C, iters, dev, rng=np.random.RandomState(4))
+    a, b = x.clone(), x.clone()
+    ops.ot_loop("chol", a, sty, R32, Rt32)
+    ops.ot_loop("chol", b, sty, R32, Rt32, fuse_rotations=2)
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
