@@ -106,23 +106,37 @@ __global__ __launch_bounds__(256) void minmax_from_parts_kernel(const float* __r
                                                                 int parts, int C, int ncols, const float* __restrict__ omn,
                                                                 const float* __restrict__ omx, int o_n_seg,
                                                                 float* __restrict__ mn, float* __restrict__ mx) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    const int seg = col / C, c = col % C;
-    const float* a = pmn + (size_t)seg * parts * C + c;
-    const float* b = pmx + (size_t)seg * parts * C + c;
+    // 64 columns per block (coalesced along the channel), 4 threads per column over interleaved partials
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
     float lo = INFINITY, hi = -INFINITY;
-    for (int p = 0; p < parts; p++) {
-        lo = fminf(lo, a[(size_t)p * C]);
-        hi = fmaxf(hi, b[(size_t)p * C]);
+    int seg = 0, c = 0;
+    if (col < ncols) {
+        seg = col / C;
+        c = col % C;
+        const float* a = pmn + (size_t)seg * parts * C + c;
+        const float* b = pmx + (size_t)seg * parts * C + c;
+#pragma unroll 8
+        for (int p = g; p < parts; p += 4) {
+            lo = fminf(lo, a[(size_t)p * C]);
+            hi = fmaxf(hi, b[(size_t)p * C]);
+        }
     }
-    if (omn) {
-        const int oc = ((o_n_seg == 1) ? 0 : seg) * C + c;
-        lo = fminf(lo, omn[oc]);
-        hi = fmaxf(hi, omx[oc]);
+    __shared__ float slo[4][64], shi[4][64];
+    slo[g][cl] = lo;
+    shi[g][cl] = hi;
+    __syncthreads();
+    if (g == 0 && col < ncols) {
+        lo = fminf(fminf(slo[0][cl], slo[1][cl]), fminf(slo[2][cl], slo[3][cl]));
+        hi = fmaxf(fmaxf(shi[0][cl], shi[1][cl]), fmaxf(shi[2][cl], shi[3][cl]));
+        if (omn) {
+            const int oc = ((o_n_seg == 1) ? 0 : seg) * C + c;
+            lo = fminf(lo, omn[oc]);
+            hi = fmaxf(hi, omx[oc]);
+        }
+        mn[col] = lo;
+        mx[col] = hi;
     }
-    mn[col] = lo;
-    mx[col] = hi;
 }
 
 __global__ void minmax_init_kernel(float* mn, float* mx, int ncols) {
@@ -439,7 +453,7 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
         const int ncols = C * n_seg;
         // reads the partials (parts / n of the map's bytes) instead of the map
         ProfScope prof(KC_MINMAX, st, 0.0, 8.0 * (double)parts * ncols);
-        hipLaunchKernelGGL(minmax_from_parts_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, tmn_parts, tmx_parts, parts, C,
+        hipLaunchKernelGGL(minmax_from_parts_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, tmn_parts, tmx_parts, parts, C,
                            ncols, w.smn, w.smx, src_n_seg, w.lo, w.hi);
         if ((rc = check_launch("minmax_from_parts_kernel"))) return rc;
     } else if ((rc = launch_minmax(target, ldt, tss, nt, C, n_seg, w.smn, w.smx, src_n_seg, w.lo, w.hi, st))) {

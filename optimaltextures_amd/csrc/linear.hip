@@ -5,6 +5,8 @@
 // instead of 2*n*C^2) and mirrored in the finalize kernel.  Centring happens while staging tiles into LDS, exactly
 // like the reference centres before the GEMM (no E[x^2] - mu^2 cancellation).  Partials of the K (= pixel) split
 // are reduced in a fixed order, so the result is deterministic.
+#include <cstdlib>
+
 #include "optex_common.h"
 
 namespace optex {
@@ -44,13 +46,19 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__
 // (GemmArgs::rowstat = 2: part [n_seg][parts][C]), summed in double in a fixed order
 __global__ __launch_bounds__(256) void mean_from_parts_kernel(const float* __restrict__ psum, int parts, int C, int ncols, long n,
                                                               float* __restrict__ mu) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    const int seg = col / C, c = col % C;
-    const float* a = psum + (size_t)seg * parts * C + c;
+    // 64 columns per block (coalesced along the channel), 4 threads per column over interleaved partials
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int p = 0; p < parts; p++) s += (double)a[(size_t)p * C];
-    mu[col] = (float)(s / (double)n);
+    if (col < ncols) {
+        const float* a = psum + (size_t)(col / C) * parts * C + (col % C);
+#pragma unroll 8
+        for (int p = g; p < parts; p += 4) s += (double)a[(size_t)p * C];
+    }
+    __shared__ double sh[4][64];
+    sh[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && col < ncols) mu[col] = (float)(((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl])) / (double)n);
 }
 
 // grid = (tile pairs, splits, n_seg).  part[seg][split][C][C] receives the (ti, tj) tile of this pixel range.
@@ -146,10 +154,13 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ x, 
 // The same on 128 x 128 output tiles (C > 64): every wave owns a 64 x 64 block = 2 x 2 MFMA tiles, so an LDS fragment
 // feeds two MFMAs instead of one, and a 256-channel map is covered by 3 tile pairs that read 768 rows from L2 instead of
 // 10 pairs reading 1280.  On a diagonal pair the wave below the diagonal (wi = 1, wj = 0) would only recompute the mirror
-// image of its neighbour: it stores nothing and skips its MFMAs.  Dynamic LDS: 2 x 2 x 128 x 33 floats = 66 KiB.
+// image of its neighbour: it stores nothing and skips its MFMAs.  GK pixels per staged chunk; dynamic LDS:
+// 2 x 2 x 128 x (GK + 1) floats = 66 KiB (GK = 32, two blocks per CU) or 34 KiB (GK = 16, four blocks per CU).
+template <int GK>
 __global__ __launch_bounds__(256) void gram128_kernel(const float* __restrict__ x, long ld, long seg_stride, long n, int C,
                                                       const float* __restrict__ mu, long chunk, int tiles,
                                                       float* __restrict__ part, int vec) {
+    constexpr int GSTR = GK + 1;
     extern __shared__ __align__(16) float g_smem[];
     float* Xi = g_smem;                       // [2][GT2 * GSTR]
     float* Xj = g_smem + 2 * GT2 * GSTR;      // [2][GT2 * GSTR]
@@ -169,45 +180,55 @@ __global__ __launch_bounds__(256) void gram128_kernel(const float* __restrict__ 
     const bool mirror = diag && wi > wj;      // uniform per wave
 
     constexpr int NQ = GT2 * GK / 4 / 256;    // float4 per operand per thread and chunk
+    // a thread stages the same NQ rows of each operand in every chunk: their means are read once.  Launched only with
+    // 16-byte aligned rows and n % 4 == 0, so every load is one unconditional float4 (clamped address, zeroed by selects
+    // past the end of this block's pixel range): all 2 * NQ loads of a chunk are in flight together — the first build
+    // branched per load on the tail and serialised a mean load, a wait, a data load and another wait per row.
+    float mi[NQ], mj[NQ];
+    const float* rowi[NQ];
+    const float* rowj[NQ];
+    bool oki[NQ], okj[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int row = (tid + q * 256) / (GK / 4);
+        const int ci = ti * GT2 + row, cj = tj * GT2 + row;
+        oki[q] = ci < C;
+        okj[q] = cj < C;
+        mi[q] = oki[q] ? mus[ci] : 0.f;
+        mj[q] = okj[q] ? mus[cj] : 0.f;
+        rowi[q] = xs + (size_t)(oki[q] ? ci : 0) * ld;
+        rowj[q] = xs + (size_t)(okj[q] ? cj : 0) * ld;
+    }
     float4 ri[NQ], rj[NQ];
+    auto centred = [&](float4 v, float m, bool ok, long pp) {
+        v.x = (ok && pp + 0 < p_end) ? v.x - m : 0.f;
+        v.y = (ok && pp + 1 < p_end) ? v.y - m : 0.f;
+        v.z = (ok && pp + 2 < p_end) ? v.z - m : 0.f;
+        v.w = (ok && pp + 3 < p_end) ? v.w - m : 0.f;
+        return v;
+    };
     auto load_global = [&](long p0) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const long pp = p0 + ((tid + q * 256) % (GK / 4)) * 4;
+            const long pc = pp < n ? pp : 0;
+            ri[q] = *reinterpret_cast<const float4*>(rowi[q] + pc);
+            if (!diag) rj[q] = *reinterpret_cast<const float4*>(rowj[q] + pc);
+        }
+    };
+    auto store_lds = [&](int buf, long p0) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const int idx = tid + q * 256;
             const int row = idx / (GK / 4), px = (idx % (GK / 4)) * 4;
             const long pp = p0 + px;
-#pragma unroll
-            for (int which = 0; which < 2; which++) {
-                if (which && diag) continue;  // a diagonal pair stages one operand and reads it twice
-                const int ch = (which ? tj : ti) * GT2 + row;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ch < C) {
-                    const float* p = xs + (size_t)ch * ld + pp;
-                    const float m = mus[ch];
-                    if (vec && pp + 3 < p_end) {
-                        v = *reinterpret_cast<const float4*>(p);
-                        v.x -= m; v.y -= m; v.z -= m; v.w -= m;
-                    } else {
-                        if (pp + 0 < p_end) v.x = p[0] - m;
-                        if (pp + 1 < p_end) v.y = p[1] - m;
-                        if (pp + 2 < p_end) v.z = p[2] - m;
-                        if (pp + 3 < p_end) v.w = p[3] - m;
-                    }
-                }
-                if (which) rj[q] = v; else ri[q] = v;
-            }
-        }
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const int idx = tid + q * 256;
-            const int row = idx / (GK / 4), px = (idx % (GK / 4)) * 4;
+            const float4 vi = centred(ri[q], mi[q], oki[q], pp);
             float* di = &Xi[buf * GT2 * GSTR + row * GSTR + px];
-            di[0] = ri[q].x; di[1] = ri[q].y; di[2] = ri[q].z; di[3] = ri[q].w;
+            di[0] = vi.x; di[1] = vi.y; di[2] = vi.z; di[3] = vi.w;
             if (!diag) {
+                const float4 vj = centred(rj[q], mj[q], okj[q], pp);
                 float* dj = &Xj[buf * GT2 * GSTR + row * GSTR + px];
-                dj[0] = rj[q].x; dj[1] = rj[q].y; dj[2] = rj[q].z; dj[3] = rj[q].w;
+                dj[0] = vj.x; dj[1] = vj.y; dj[2] = vj.z; dj[3] = vj.w;
             }
         }
     };
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(256) void gram128_kernel(const float* __restrict__ 
     const long nchunks = (p_end - p_beg + GK - 1) / GK;
     if (nchunks > 0) {
         load_global(p_beg);
-        store_lds(0);
+        store_lds(0, p_beg);
     }
     __syncthreads();
     for (long kc = 0; kc < nchunks; kc++) {
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(256) void gram128_kernel(const float* __restrict__ 
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
-        if (kc + 1 < nchunks) store_lds(buf ^ 1);
+        if (kc + 1 < nchunks) store_lds(buf ^ 1, p_beg + (kc + 1) * GK);
         __syncthreads();
     }
     if (mirror) return;
@@ -280,10 +301,9 @@ __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n
 
 int device_cu_count();
 
-static int gram_splits(long n, int C, int n_seg) {
+static int gram_splits(long n, int C, int n_seg, bool big) {
     // 64-tiles: two blocks' worth of work per CU; 128-tiles (two resident blocks per CU, long blocks): about four rounds of
     // resident blocks, so that the last round's idle CUs cost a few per cent instead of a third
-    const bool big = C > GT;
     const int gt = big ? GT2 : GT;
     const int tiles = (C + gt - 1) / gt, pairs = tiles * (tiles + 1) / 2;
     const long target = (big ? 6L : 2L) * device_cu_count();
@@ -323,7 +343,7 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
     const int vec = aligned16(x) && ld % 4 == 0 && seg_stride % 4 == 0;
     if (sum_parts) {
         ProfScope prof(KC_MEAN, st, 0.0, 4.0 * (double)parts * C * n_seg);
-        hipLaunchKernelGGL(mean_from_parts_kernel, dim3((C * n_seg + 255) / 256), dim3(256), 0, st, sum_parts, parts, C,
+        hipLaunchKernelGGL(mean_from_parts_kernel, dim3((C * n_seg + 63) / 64), dim3(256), 0, st, sum_parts, parts, C,
                            C * n_seg, n, mu);
     } else {
         ProfScope prof(KC_MEAN, st, 0.0, 4.0 * (double)n * C * n_seg);
@@ -331,10 +351,10 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
     }
     int rc = check_launch("col_mean_kernel");
     if (rc) return rc;
-    const bool big = C > GT;
+    const bool big = C > GT && vec && n % 4 == 0;  // the 128-tile kernel loads unconditional float4s
     const int gt = big ? GT2 : GT;
     const int tiles = (C + gt - 1) / gt, pairs = tiles * (tiles + 1) / 2;
-    const int splits = gram_splits(n, C, n_seg);
+    const int splits = gram_splits(n, C, n_seg, big);
     long chunk = (n + splits - 1) / splits;
     chunk = (chunk + GK - 1) / GK * GK;  // chunk starts stay multiples of 4 pixels (float4 loads)
     float* part = static_cast<float*>(ws);
@@ -344,21 +364,26 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
         const int b64 = (C + GT - 1) / GT;
         ProfScope prof(KC_GRAM, st, 2.0 * (b64 * (b64 + 1) / 2) * GT * GT * (double)n * n_seg, 4.0 * (double)n * C * n_seg);
         if (big) {
-            const size_t lds = (size_t)4 * GT2 * GSTR * sizeof(float);
-            static bool attr_done[64] = {};
+            static const int gk = [] {
+                const char* e = getenv("OPTEX_GRAM_GK");
+                return (e && atoi(e) == 16) ? 16 : 32;
+            }();
+            const size_t lds = (size_t)4 * GT2 * (gk + 1) * sizeof(float);
+            auto kern = gk == 32 ? gram128_kernel<32> : gram128_kernel<16>;
+            static bool attr_done[64][2] = {};
             int dev = 0;
             (void)hipGetDevice(&dev);
-            if (!attr_done[dev & 63]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram128_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (!attr_done[dev & 63][gk == 32]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds);
                 if (e != hipSuccess) {
                     set_error("gram128_kernel: cannot reserve LDS: %s", hipGetErrorString(e));
                     return OPTEX_E_LAUNCH;
                 }
-                attr_done[dev & 63] = true;
+                attr_done[dev & 63][gk == 32] = true;
             }
-            hipLaunchKernelGGL(gram128_kernel, dim3(pairs, splits, n_seg), dim3(256), lds, st, x, ld, seg_stride, n, C, mu,
-                               chunk, tiles, part, vec);
+            hipLaunchKernelGGL(kern, dim3(pairs, splits, n_seg), dim3(256), lds, st, x, ld, seg_stride, n, C, mu, chunk, tiles,
+                               part, vec);
         } else {
             hipLaunchKernelGGL(gram_kernel, dim3(pairs, splits, n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, chunk,
                                tiles, part, vec);

@@ -39,7 +39,6 @@ struct SortArgs {
     double inv_2nt;                                           // 1 / (2 * n) for the quantile index
     int ncols;                                                // C * n_seg
     int out_vec;                                              // rank_match_kernel: `out` takes 16-byte stores
-    int prefetch_ahead;                                       // rank_match3_kernel: column col + this is pulled towards the L2
 #ifdef R2_DEBUG
     uint32_t* dbg;                                            // scripts/sort_rank2_debug.hip
 #endif

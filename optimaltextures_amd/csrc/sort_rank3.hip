@@ -24,8 +24,6 @@
 // all-equal (the zeros of un-rotated ReLU features): ranks = ranks of the pixel indices (bitmap + popcount prefix).
 // Anything else (non-finite keys, many distinct massive ties, queue overflow) flags the column for the radix kernel of
 // sort.hip, which runs right behind this one on the stream.
-#include <cstdlib>
-
 #include "sort_common.h"
 
 namespace optex {
@@ -385,16 +383,6 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         __syncthreads();
     }
     SORT_PROBE(6);
-    // The column of the workgroup that will take this one's place on the CU (blocks are handed out in order: the resident
-    // set is ~2 per CU, so that is column col + resident, same XCD = same L2) is pulled towards the L2 now: one dword per
-    // 64 bytes, result unused.  Its own loads then meet an L2 / Infinity-Cache hit instead of an HBM round trip under load
-    // (load + min/max: 8 of the 42 us a column occupies its half of a CU).  Speed only — a wrong guess costs one load.
-    float sink = 0.f;  // consumed by a store that never happens (at the very end): the load stays in flight until then
-    if (a.prefetch_ahead > 0 && col + a.prefetch_ahead < a.ncols) {
-        const int pc = col + a.prefetch_ahead, pseg = pc / a.C, pch = pc % a.C;
-        const float* nsrc = a.keys + (size_t)((a.x_n_seg == 1) ? 0 : pseg) * a.ss + (size_t)pch * a.ld;
-        sink = nsrc[tid * 16 < n ? tid * 16 : 0];  // n <= 16384: one dword per thread covers the column
-    }
     // ---- 7. ranks, owner side: every slot before the bucket holds a smaller key, every slot behind it a larger one, so
     //         rank = W0 + #{slot[W0 .. W0 + 7] < key} for the aligned window W0 = start & ~3 whenever it covers the bucket.
     //         ba[r] becomes the rank (or R3_TAG | queue entry).
@@ -533,18 +521,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (int r = 0; r < ITEMS; r++)
             if (valid(r)) o[elem(r)] = v[r];
     }
-    if (a.ncols < 0) o[0] = sink;  // never true
     SORT_PROBE(10);
-}
-
-// OPTEX_SORT_PREFETCH = number of columns ahead whose data the kernel pulls towards the L2 (default: the resident set,
-// 2 per CU; 0 = off)
-static int prefetch_ahead_env() {
-    static const int v = [] {
-        const char* e = getenv("OPTEX_SORT_PREFETCH");
-        return e ? atoi(e) : -1;
-    }();
-    return v;
 }
 
 template <int ITEMS>
@@ -553,7 +530,6 @@ static int launch_rank_match3_items(SortArgs a, int ncols, hipStream_t st) {
                         (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
     a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
     const size_t lds = R3<ITEMS>::LDS;
-    a.prefetch_ahead = prefetch_ahead_env() < 0 ? 2 * device_cu_count() : prefetch_ahead_env();
     hipError_t e;
     if (in_vec) {
         auto kern = rank_match3_kernel<ITEMS, (ITEMS >= 4)>;

@@ -19,7 +19,9 @@ import re
 CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"),
             ("col_hist_kernel", "col_hist"), ("col_minmax_kernel", "col_minmax"), ("cdf_lut_kernel", "cdf_lut"),
             ("glue_kernel", "vgg_glue"), ("glue_nhwc_kernel", "vgg_glue"), ("glue_transpose", "vgg_glue"),
-            ("rank_match_kernel", "sort_match"), ("rank_columns_kernel", "sort_rank"), ("sort_columns_kernel", "sort_radix"), ("gram_kernel", "gram"),
+            ("rank_match_kernel", "sort_match"), ("rank_match3_kernel", "sort_match"), ("rank_columns_kernel", "sort_rank"),
+            ("gram128_kernel", "gram"), ("minmax_from_parts_kernel", "col_minmax"), ("mean_from_parts_kernel", "col_mean"),
+            ("chol_inv_kernel", "chol_inv"), ("ns_init_kernel", "ns_init"), ("cov_finalize_kernel", "cov_finalize"), ("sort_columns_kernel", "sort_radix"), ("gram_kernel", "gram"),
             ("col_mean_kernel", "col_mean"), ("householder_apply", "householder")]
 
 
@@ -51,8 +53,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default="")
+    ap.add_argument("--measured", default="", help="what / when this was measured on (round, commit), copied into the file")
     args = ap.parse_args()
-    out = {"command": args.command, "units": "bytes per launch, averaged over the launches of the timed steps",
+    out = {"command": args.command, "measured": args.measured, "units": "bytes per launch, averaged over the launches of the timed steps",
            "corrections": {"FETCH_SIZE": "x1024 x2 (gfx950 counts 128-B requests as 64 B on wide streaming reads)",
                            "WRITE_SIZE": "x1024"}, "kernels": {}}
     for path, counter, scale in ((args.fetch_csv, "FETCH_SIZE", 2048.0), (args.write_csv, "WRITE_SIZE", 1024.0)):
