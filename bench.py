@@ -171,9 +171,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="independent textures per GPU per step (16 / 32 / 64 measured: 176 / 183 / 198 textures/s)")
     ap.add_argument("--hist_mode", type=str, default="cdf", choices=["cdf", "sort", "chol", "pca", "sym"])
-    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,refdefaults",
+    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,refdefaults,assets",
                     help="one extra step each (N = 1 only); 'fused' = the labelled re-association fast paths, "
-                         "'refdefaults' = chol + PCA + pooled batch (the reference's own defaults)")
+                         "'refdefaults' = chol + PCA + pooled batch (the reference's own defaults), 'assets' = the headline "
+                         "configuration on the reference's real relu3_1 weights and style/graffiti.jpg (assets/)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
     ap.add_argument("--no_miopen_find", action="store_true", help="torch.backends.cudnn.benchmark = False: MIOpen picks the convolution kernels from its heuristics / find-db instead of timing every solver in the warm-up step")
@@ -322,6 +323,31 @@ def main():
                 result["textures_per_s_reference_defaults"] = {
                     "value": round(B / (time.perf_counter() - t0), 3),
                     "config": f"hist_mode=chol, PCA on, batch of {B} pooled into one distribution (reference --batch semantics)"}
+        models, graffiti = os.path.join(ROOT, "assets", "models"), os.path.join(ROOT, "assets", "style", "graffiti.jpg")
+        if "assets" in args.other_modes.split(",") and os.path.isdir(models) and os.path.exists(graffiti):
+            # the same step on REAL data (the headline uses synthetic weights and a synthetic style, as the bench contract
+            # asks): the reference's pretrained relu3_1 encoder / decoder and its default style image — data-dependent
+            # paths (sort's flagged columns, histogram shapes) see real feature statistics here
+            from optimaltextures_amd.util import load_styles
+            real = {}
+            with torch.inference_mode():
+                real_style = load_styles([graffiti], size=SIZE, scale=1.0, device=device)[0]
+                for mode in dict.fromkeys([args.hist_mode, "sort", "chol"]):
+                    m = OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode=mode, no_pca=True, layers=(LAYER,),
+                                       independent=True, models_dir=models).to(device).eval()
+                    m.rng = np.random.RandomState(1000)
+                    for timed in (False, True):
+                        pastiche = torch.rand((B, 3, SIZE, SIZE), device=device, generator=gen)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        out = m.forward(pastiche, [real_style])
+                        torch.cuda.synchronize()
+                        if timed:
+                            real[mode] = round(B / (time.perf_counter() - t0), 3)
+                    assert torch.isfinite(out).all()
+            result["textures_per_s_real_assets"] = {
+                "by_hist_mode": real,
+                "config": "pretrained relu3_1 weights + style/graffiti.jpg from assets/ (the reference's files), otherwise the headline configuration"}
         if not args.no_cpu_baseline:
             # more threads than ~32 only add oversubscription to torch-CPU convs and the OpenMP oracle (measured on the
             # 256-core GPU host: 256 threads were 5x slower than 8); `cores` reports what was actually used

@@ -285,22 +285,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // EXTRA = true adds the operand centring (bsub), the output bias (badd) and the content blend of the general kernel, with
 // the same arithmetic in the same order (bit-identical to gemm_tn_kernel): the apply GEMM of the linear modes
 // (histmatch.py:27/34/42,44) and the blending inverse rotation of style transfer (optex.py:115-117, 175) take this path too.
-// ROWSTAT: 0 = off, 1 = per-row min / max, 2 = per-row sum of the outputs (GemmArgs::rowstat), reduced over the wave's pixel
-// columns in registers (4 tiles in-lane, then 16 lanes with DPP butterflies) — ~1.5 % more issue slots than the MFMAs
-// of a 256-deep tile, instead of a separate pass that re-reads the whole rotated map from HBM.
-__device__ __forceinline__ float row16_min(float v) {
-    v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2)); v = fminf(v, __shfl_xor(v, 4)); v = fminf(v, __shfl_xor(v, 8));
-    return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
-    return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v = v + __shfl_xor(v, 1); v = v + __shfl_xor(v, 2); v = v + __shfl_xor(v, 4); v = v + __shfl_xor(v, 8);
-    return v;
-}
-
+// ROWSTAT: 0 = off, 1 = per-row min / max, 2 = per-row sum of the outputs (GemmArgs::rowstat), reduced over the wave's 64
+// pixel columns in registers (16 in-lane, then two cross-lane steps) instead of a separate pass that re-reads the whole
+// rotated map from HBM.
 template <int BM, int BN, int BK, int WGM, int WGN, bool EXTRA, int ROWSTAT = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
@@ -385,109 +372,90 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
             for (int tm = 0; tm < TM; tm++)
 #pragma unroll
                 for (int tn = 0; tn < TN; tn++)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tn], av[tm], acc[tm][tn], 0, 0, 0);
         }
         if (kc + 1 < nchunks) store_lds(buf ^ 1);
         __syncthreads();
     }
-    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+    // The MFMA is fed (B fragment, A fragment), i.e. it computes the TRANSPOSED 16 x 16 block: in its C/D layout
+    // (col = lane & 15, row = 4 * (lane >> 4) + r) a lane then holds FOUR CONSECUTIVE PIXELS (r) of ONE channel (lane & 15),
+    // so the tile leaves with 16-byte stores along the pixel rows (16 store instructions per wave instead of 64 dword
+    // stores) and the bias / content of a lane are one scalar / one 16-byte load.  Every output element is still the same
+    // k-ordered fma chain (a * b commutes exactly): bit-identical to the other operand order.
     float* __restrict__ Op = a.O + (size_t)seg * a.o_ss;
     const float* __restrict__ Cp = (EXTRA && a.content) ? a.content + (size_t)seg * a.o_ss : nullptr;
     const float* __restrict__ badd = (EXTRA && a.badd) ? a.badd + (size_t)seg * a.badd_ss : nullptr;
     const float strength = a.strength;
-    if (!EXTRA) {
 #pragma unroll
-        for (int tm = 0; tm < TM; tm++)
+    for (int tm = 0; tm < TM; tm++) {
+        const int m = m0 + wm * WM + tm * 16 + l15;
+        const bool ok = m < a.M;
+        const size_t row = (size_t)(ok ? m : 0) * a.ldo;
+        float bias = 0.f;
+        if (EXTRA && badd) bias = badd[ok ? m : 0];
+        float4 cv[TN];
+        if (EXTRA && Cp) {  // the content values of this lane, in flight together
 #pragma unroll
-            for (int tn = 0; tn < TN; tn++) {
-                const long nn = n0 + wn * WN + tn * 16 + l15;
+            for (int tn = 0; tn < TN; tn++)
+                cv[tn] = *reinterpret_cast<const float4*>(Cp + row + n0 + wn * WN + tn * 16 + 4 * kq);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) {
+            const long nn = n0 + wn * WN + tn * 16 + 4 * kq;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                v[r] = acc[tm][tn][r];
+                if (EXTRA && badd) v[r] = v[r] + bias;
+            }
+            if (EXTRA && Cp) {  // same arithmetic in the same order as gemm_tn_kernel: v + strength * (content - v)
+                const float c[4] = {cv[tn].x, cv[tn].y, cv[tn].z, cv[tn].w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int m = m0 + wm * WM + tm * 16 + 4 * kq + r;
-                    if (m < a.M) Op[(size_t)m * a.ldo + nn] = acc[tm][tn][r];
+                    const float d = c[r] - v[r];
+                    const float sd = strength * d;
+                    v[r] = v[r] + sd;
                 }
             }
-    } else {
-        // Bias and content blend, the same arithmetic in the same order as gemm_tn_kernel (v + badd, then
-        // v + strength * (content - v)), but with the loads of a 16-row group issued together and no per-element
-        // branches: the first build loaded, waited and stored element by element (64 serialised L2 round trips per
-        // lane; +23 % on the apply GEMM of the linear modes, +20 % on the blending inverse rotation).  M % 4 == 0 on this
-        // path, so the four rows of an accumulator stand or fall together.
-#pragma unroll
-        for (int tm = 0; tm < TM; tm++) {
-            const int mb = m0 + wm * WM + tm * 16 + 4 * kq;
-            const bool ok = mb < a.M;
-            const int mc = ok ? mb : 0;
-            float bias[4] = {0.f, 0.f, 0.f, 0.f};
-            if (badd) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) bias[r] = badd[mc + r];
-            }
-            if (Cp) {
-                float cv[TN][4];
-#pragma unroll
-                for (int tn = 0; tn < TN; tn++) {
-                    const long nn = n0 + wn * WN + tn * 16 + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) cv[tn][r] = Cp[(size_t)(mc + r) * a.ldo + nn];
-                }
-#pragma unroll
-                for (int tn = 0; tn < TN; tn++) {
-                    const long nn = n0 + wn * WN + tn * 16 + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float v = acc[tm][tn][r];
-                        if (badd) v = v + bias[r];
-                        const float d = cv[tn][r] - v;
-                        const float sd = strength * d;
-                        v = v + sd;
-                        if (ok) Op[(size_t)(mb + r) * a.ldo + nn] = v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int tn = 0; tn < TN; tn++) {
-                    const long nn = n0 + wn * WN + tn * 16 + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float v = acc[tm][tn][r];
-                        if (badd) v = v + bias[r];
-                        if (ok) Op[(size_t)(mb + r) * a.ldo + nn] = v;
-                    }
-                }
-            }
+            if (ok) *reinterpret_cast<float4*>(Op + row + nn) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     if (ROWSTAT != 0) {
         // one partial per (pixel tile, wave column): [seg][tn_idx * WGN + wn][m]; the statistics are those of the plain
-        // product (this path is only taken without bias / blend)
+        // product (this path is only taken without bias / blend).  In-lane over the lane's 16 pixels, then over the four
+        // lane groups that hold the other pixels of the same channel.
         const size_t pbase = ((size_t)seg * a.tiles_n * WGN + (size_t)tn_idx * WGN + wn) * a.M;
 #pragma unroll
-        for (int tm = 0; tm < TM; tm++)
+        for (int tm = 0; tm < TM; tm++) {
+            const int m = m0 + wm * WM + tm * 16 + l15;
+            if (ROWSTAT == 1) {
+                float mn = acc[tm][0][0], mx = acc[tm][0][0];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int m = m0 + wm * WM + tm * 16 + 4 * kq + r;
-                if (ROWSTAT == 1) {
-                    float mn = acc[tm][0][r], mx = acc[tm][0][r];
+                for (int tn = 0; tn < TN; tn++)
 #pragma unroll
-                    for (int tn = 1; tn < TN; tn++) {
+                    for (int r = 0; r < 4; r++) {
                         mn = fminf(mn, acc[tm][tn][r]);
                         mx = fmaxf(mx, acc[tm][tn][r]);
                     }
-                    mn = row16_min(mn);
-                    mx = row16_max(mx);
-                    if (l15 == 0 && m < a.M) {
-                        a.rs_a[pbase + m] = mn;
-                        a.rs_b[pbase + m] = mx;
-                    }
-                } else {
-                    float sm = acc[tm][0][r];
-#pragma unroll
-                    for (int tn = 1; tn < TN; tn++) sm = sm + acc[tm][tn][r];
-                    sm = row16_sum(sm);
-                    if (l15 == 0 && m < a.M) a.rs_a[pbase + m] = sm;
+                mn = fminf(mn, __shfl_xor(mn, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mn = fminf(mn, __shfl_xor(mn, 32));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (kq == 0 && m < a.M) {
+                    a.rs_a[pbase + m] = mn;
+                    a.rs_b[pbase + m] = mx;
                 }
+            } else {
+                float sm = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sm = sm + acc[tm][tn][r];
+                sm = sm + __shfl_xor(sm, 16);
+                sm = sm + __shfl_xor(sm, 32);
+                if (kq == 0 && m < a.M) a.rs_a[pbase + m] = sm;
             }
+        }
     }
 }
 
@@ -526,6 +494,13 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
 // draws 1350 W of its 1400 W cap (rocm-smi), so the kernel is power-limited, not issue-limited.
 int device_cu_count();
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the hot-loop kernel stores (and reads the content) in 16-byte pieces along the pixel rows
+static bool output_vec(const GemmArgs& a) {
+    return aligned16(a.O) && a.ldo % 4 == 0 && a.o_ss % 4 == 0 && (!a.content || aligned16(a.content));
+}
+
 // shapes the hot-loop kernel (gemm16_cm_kernel, 256 x 128 tiles) takes; layouts and alignment are checked by the callers
 static bool hot_shape(const GemmArgs& a, int n_cu) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
@@ -540,7 +515,7 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     if (a.sym) return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);  // square tiles: the mirrored store needs BM == BN
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
-        if (!BPM && !OPM && vec && hot_shape(a, n_cu)) {
+        if (!BPM && !OPM && vec && hot_shape(a, n_cu) && output_vec(a)) {
             a.tiles_m = (a.M + 255) / 256;
             a.tiles_n = (int)(a.n / 128);
             const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
@@ -563,14 +538,12 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);
 }
 
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 static bool operands_vec(const GemmArgs& a) {
     return aligned16(a.At) && a.lda % 4 == 0 && a.at_ss % 4 == 0 && aligned16(a.B) && a.ldb % 4 == 0 && a.b_ss % 4 == 0;
 }
 
 bool gemm_rowstat_supported(const GemmArgs& a) {
-    return operands_vec(a) && !a.bsub && !a.badd && !a.content && hot_shape(a, device_cu_count());
+    return operands_vec(a) && output_vec(a) && !a.bsub && !a.badd && !a.content && hot_shape(a, device_cu_count());
 }
 
 int gemm_rowstat_parts(long n) { return (int)(n / 128) * 2; }  // pixel tiles of 128 x the block's two wave columns

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         uint32_t bw[G4], bb[G4], old[G4];
 #pragma unroll
         for (int j = 0; j < G4; j++) {
+            if (g + j >= ITEMS) continue;  // compile-time: ITEMS need not be a multiple of four
             const float t = (key2f(key[g + j]) - lo) * s1;
             int bin = (int)t;
             bin = bin > RK_COARSE - 1 ? RK_COARSE - 1 : bin;
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
 #pragma unroll
         for (int j = 0; j < G4; j++) {
+            if (g + j >= ITEMS) continue;
             const int wd = (int)(bw[j] >> 16);
             const float u = fr[j] * (float)wd;
             int sub = (int)u;
@@ -265,13 +267,16 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
 #pragma unroll
         for (int j = 0; j < G4; j++)
-            old[j] = atomicAdd(&cnt[bb[j] >> 1], (valid(g + j) ? 1u : 0u) << ((bb[j] & 1u) << 4));
+            if (g + j < ITEMS) old[j] = atomicAdd(&cnt[bb[j] >> 1], (valid(g + j) ? 1u : 0u) << ((bb[j] & 1u) << 4));
 #pragma unroll
-        for (int j = 0; j < G4; j++) ba[g + j] = bb[j] | (((old[j] >> ((bb[j] & 1u) << 4)) & 0xffffu) << R3_BBITS);
+        for (int j = 0; j < G4; j++)
+            if (g + j < ITEMS) ba[g + j] = bb[j] | (((old[j] >> ((bb[j] & 1u) << 4)) & 0xffffu) << R3_BBITS);
         // the (b, a) words packed here: otherwise the compiler keeps b and the atomic's result apart until step 6 and
         // spills both (64-VGPR budget)
-        if (G4 == 4) asm volatile("" : "+v"(ba[g]), "+v"(ba[g + 1]), "+v"(ba[g + 2]), "+v"(ba[g + 3]) : : "memory");
-        else asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < G4; j++)
+            if (g + j < ITEMS) asm volatile("" : "+v"(ba[g + j]));
+        asm volatile("" ::: "memory");
     }
     __syncthreads();
     SORT_PROBE(4);
@@ -337,9 +342,11 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     for (int g = 0; g < ITEMS; g += G4) {
         uint32_t e[G4];
 #pragma unroll
-        for (int j = 0; j < G4; j++) e[j] = st16[ba[g + j] & ((1u << R3_BBITS) - 1u)];
+        for (int j = 0; j < G4; j++)
+            if (g + j < ITEMS) e[j] = st16[ba[g + j] & ((1u << R3_BBITS) - 1u)];
 #pragma unroll
         for (int j = 0; j < G4; j++) {
+            if (g + j >= ITEMS) continue;
             const uint32_t arr = ba[g + j] >> R3_BBITS;
             slot[valid(g + j) ? (e[j] & R3_SMASK) + arr : (uint32_t)(CAP + R3_QWIN)] = key[g + j];
             ba[g + j] = e[j];
@@ -386,37 +393,38 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // ---- 7. ranks, owner side: every slot before the bucket holds a smaller key, every slot behind it a larger one, so
     //         rank = W0 + #{slot[W0 .. W0 + 7] < key} for the aligned window W0 = start & ~3 whenever it covers the bucket.
     //         ba[r] becomes the rank (or R3_TAG | queue entry).
-#pragma unroll
-    for (int g = 0; g < ITEMS; g += 2) {
-        uint4 x0[2], x1[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint4* wp = reinterpret_cast<const uint4*>(slot + (ba[g + j] & (R3_SMASK & ~3u)));
-            x0[j] = wp[0];
-            x1[j] = wp[1];
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int r = g + j;
-            const uint32_t e = ba[r], k = key[r];
-            const uint32_t w0p = e & (R3_SMASK & ~3u);
-            uint32_t lt = 0u, le = 0u;
-            r3_window(lt, le, x0[j], x1[j], k);
-            const bool done = (e & R3_DONE) != 0u;
-            // a bucket wider than the window, or another slot with the same key (the pixels decide): the queue
-            const bool queued = valid(r) && !done && ((e & R3_LONG) != 0u || le - lt > 1u);
-            uint32_t qi = 0u;
-            if (queued) {
-                qi = atomicAdd(&misc[20], 1u);
-                if (qi < (uint32_t)QCAP) {
-                    qkey[qi] = k;
-                    qwin[qi] = w0p;
-                    qpix[qi] = (uint32_t)elem(r);
-                }
+    auto rank_one = [&](int r, const uint4& x0, const uint4& x1) {
+        const uint32_t e = ba[r], k = key[r];
+        const uint32_t w0p = e & (R3_SMASK & ~3u);
+        uint32_t lt = 0u, le = 0u;
+        r3_window(lt, le, x0, x1, k);
+        const bool done = (e & R3_DONE) != 0u;
+        // a bucket wider than the window, or another slot with the same key (the pixels decide): the queue
+        const bool queued = valid(r) && !done && ((e & R3_LONG) != 0u || le - lt > 1u);
+        uint32_t qi = 0u;
+        if (queued) {
+            qi = atomicAdd(&misc[20], 1u);
+            if (qi < (uint32_t)QCAP) {
+                qkey[qi] = k;
+                qwin[qi] = w0p;
+                qpix[qi] = (uint32_t)elem(r);
             }
-            ba[r] = queued ? (R3_TAG | qi) : (done ? (e & R3_SMASK) : w0p + lt);
         }
-        asm volatile("" ::: "memory");  // two windows in flight: keeps the unrolled loop inside the 64-VGPR budget
+        ba[r] = queued ? (R3_TAG | qi) : (done ? (e & R3_SMASK) : w0p + lt);
+    };
+#pragma unroll
+    for (int g = 0; g + 1 < ITEMS; g += 2) {  // two windows in flight: keeps the unrolled loop inside the 64-VGPR budget
+        const uint4* wa = reinterpret_cast<const uint4*>(slot + (ba[g] & (R3_SMASK & ~3u)));
+        const uint4* wb = reinterpret_cast<const uint4*>(slot + (ba[g + 1] & (R3_SMASK & ~3u)));
+        const uint4 a0 = wa[0], a1 = wa[1], b0 = wb[0], b1 = wb[1];
+        rank_one(g, a0, a1);
+        rank_one(g + 1, b0, b1);
+        asm volatile("" ::: "memory");
+    }
+    if (ITEMS & 1) {
+        const uint4* wa = reinterpret_cast<const uint4*>(slot + (ba[ITEMS - 1] & (R3_SMASK & ~3u)));
+        const uint4 a0 = wa[0], a1 = wa[1];
+        rank_one(ITEMS - 1, a0, a1);
     }
     asm volatile("" ::: "memory");
     SORT_PROBE(7);
@@ -526,13 +534,13 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 
 template <int ITEMS>
 static int launch_rank_match3_items(SortArgs a, int ncols, hipStream_t st) {
-    const bool in_vec = ITEMS >= 4 && a.n % 4 == 0 && a.ld % 4 == 0 && a.ss % 4 == 0 &&
+    const bool in_vec = ITEMS >= 4 && ITEMS % 4 == 0 && a.n % 4 == 0 && a.ld % 4 == 0 && a.ss % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
     a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
     const size_t lds = R3<ITEMS>::LDS;
     hipError_t e;
     if (in_vec) {
-        auto kern = rank_match3_kernel<ITEMS, (ITEMS >= 4)>;
+        auto kern = rank_match3_kernel<ITEMS, (ITEMS >= 4 && ITEMS % 4 == 0)>;
         static DeviceOnce once;
         bool& attr = *once.slot();
         if (!attr) {
@@ -555,13 +563,27 @@ static int launch_rank_match3_items(SortArgs a, int ncols, hipStream_t st) {
     return check_launch("rank_match3_kernel");
 }
 
-// called by launch_sort_items<ITEMS, SORT_MATCH> (sort.hip) with flags cleared and the prof scope open
+// called by launch_sort_items<ITEMS, SORT_MATCH> (sort.hip) with flags cleared and the prof scope open.  The keys per thread
+// are chosen here, as few as hold the column: registers past the end of a column still cost their instructions, so a
+// 12544-key column runs 13 keys per thread (scalar loads) rather than 16 (16-byte loads, 23 % of the slots empty).
 int launch_rank_match3(int items, const SortArgs& a, int ncols, hipStream_t st) {
-    switch (items) {
+    (void)items;
+    const int need = (int)((a.n + SORT_NT - 1) / SORT_NT);
+    switch (need < 2 ? 2 : need) {
         case 2: return launch_rank_match3_items<2>(a, ncols, st);
+        case 3: return launch_rank_match3_items<3>(a, ncols, st);
         case 4: return launch_rank_match3_items<4>(a, ncols, st);
+        case 5: return launch_rank_match3_items<5>(a, ncols, st);
+        case 6: return launch_rank_match3_items<6>(a, ncols, st);
+        case 7: return launch_rank_match3_items<7>(a, ncols, st);
         case 8: return launch_rank_match3_items<8>(a, ncols, st);
+        case 9: return launch_rank_match3_items<9>(a, ncols, st);
+        case 10: return launch_rank_match3_items<10>(a, ncols, st);
+        case 11: return launch_rank_match3_items<11>(a, ncols, st);
         case 12: return launch_rank_match3_items<12>(a, ncols, st);
+        case 13: return launch_rank_match3_items<13>(a, ncols, st);
+        case 14: return launch_rank_match3_items<14>(a, ncols, st);
+        case 15: return launch_rank_match3_items<15>(a, ncols, st);
         default: return launch_rank_match3_items<16>(a, ncols, st);
     }
 }
