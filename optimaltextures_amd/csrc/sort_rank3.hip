@@ -37,14 +37,14 @@ constexpr int R3_WIN = 8;
 constexpr int R3_QWIN = 52;                // window of a queued key, slots: covers (start & 3) + RK_BIG
 constexpr int R3_BBITS = 13;               // bucket id bits in the owner's (b, a) register
 
-template <int ITEMS>
+template <int ITEMS, int NT>
 struct R3 {
-    static constexpr int CAP = ITEMS * SORT_NT;
+    static constexpr int CAP = ITEMS * NT;
     // buckets + 1 spare per coarse bin; 16 keys per thread: what fits 80 KiB next to the 64 KiB of slots
-    static constexpr int NBT = ITEMS == 16 ? 7872 : (CAP < 8192 ? CAP : 8192);
+    static constexpr int NBT = CAP == 16384 ? 7872 : (CAP < 8192 ? CAP : 8192);
     static constexpr int NB = NBT - RK_COARSE;
     static constexpr int NW2 = NBT / 2;                               // packed u16 counters -> start entries
-    static constexpr int PER = (NW2 + SORT_NT - 1) / SORT_NT;
+    static constexpr int PER = (NW2 + NT - 1) / NT;
     static constexpr int NWORDS = CAP / 32;
     static constexpr int TCAP = 256;                                  // queue entries with an equal partner
     static constexpr int QCAP = (NW2 - TCAP) / 4;                     // key, window, pixel, result per queue entry
@@ -88,9 +88,12 @@ __device__ __forceinline__ void r3_window(uint32_t& lt, uint32_t& le, const uint
         : "vcc");
 }
 
-template <int ITEMS, bool VEC>
-__global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match3_kernel(SortArgs a) {
-    using K = R3<ITEMS>;
+// NT threads per workgroup (1024, or 512 / 256 for short columns: the per-column steps are barrier-to-barrier latency
+// chains, and smaller workgroups let more columns overlap on a CU — up to the 2048-thread limit — at 16 keys per thread)
+template <int ITEMS, bool VEC, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match3_kernel(SortArgs a) {
+    using K = R3<ITEMS, NT>;
+    constexpr int NW = NT / 64;
     constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, QCAP = K::QCAP, TCAP = K::TCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* slot = reinterpret_cast<uint32_t*>(smem);   // [CAP + 52 + 4] keys by bucket position; later the sorted source column
@@ -117,10 +120,10 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int n = (int)a.n;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // pixel held in register r: 16-byte loads put 4 neighbouring pixels into one thread
-    auto elem = [&](int r) { return VEC ? ((r >> 2) * SORT_NT + tid) * 4 + (r & 3) : r * SORT_NT + tid; };
+    auto elem = [&](int r) { return VEC ? ((r >> 2) * NT + tid) * 4 + (r & 3) : r * NT + tid; };
     // register r holds a pixel of the column (VEC: n % 4 == 0, the four pixels of a 16-byte load stand or fall together);
     // a compare of tid with a scalar, so that neither 16 pixel numbers nor 16 lane masks have to stay live
-    auto valid = [&](int r) { return VEC ? tid < (n >> 2) - (r >> 2) * SORT_NT : tid < n - r * SORT_NT; };
+    auto valid = [&](int r) { return VEC ? tid < (n >> 2) - (r >> 2) * NT : tid < n - r * NT; };
 
     SORT_PROBE(0);
     // ---- 0. the column
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (VEC) {
 #pragma unroll
         for (int q = 0; q < ITEMS / 4; q++) {
-            const int e0 = (q * SORT_NT + tid) * 4;
+            const int e0 = (q * NT + tid) * 4;
             const float4 v = *reinterpret_cast<const float4*>(src + (e0 < n ? e0 : 0));
             key[4 * q + 0] = f2key(v.x);
             key[4 * q + 1] = f2key(v.y);
@@ -138,14 +141,14 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     } else {
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
-            const int e = r * SORT_NT + tid;
+            const int e = r * NT + tid;
             key[r] = f2key(src[e < n ? e : n - 1]);
         }
     }
-    for (int i = tid; i < K::CNTW; i += SORT_NT) cnt[i] = 0u;
+    for (int i = tid; i < K::CNTW; i += NT) cnt[i] = 0u;
     if (tid < RK_COARSE) c1[tid] = 0u;
     if (tid < 32) misc[tid] = 0u;
-    if (tid >= SORT_NT - R3_QWIN) slot[n + (tid - (SORT_NT - R3_QWIN))] = 0xffffffffu;  // larger than every finite key
+    if (tid >= NT - R3_QWIN) slot[n + (tid - (NT - R3_QWIN))] = 0xffffffffu;  // larger than every finite key
 
     // ---- 1. min / max
     uint32_t klo = 0xffffffffu, khi = 0u;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SORT_NW; k++) {
+    for (int k = 0; k < NW; k++) {
         klo = red[k] < klo ? red[k] : klo;
         khi = red[16 + k] > khi ? red[16 + k] : khi;
     }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     const float lo = key2f(klo), hi = key2f(khi);
     if (klo == khi) {  // constant column: already sorted, rank = pixel index
-        for (int e = tid; e < n; e += SORT_NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+        for (int e = tid; e < n; e += NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
         return;
     }
     const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     } else {
 #pragma unroll
         for (int r = 0; r < ITEMS; r += RS) {
-            const int left = n - r * SORT_NT;
-            nsamp += (unsigned)(left < 0 ? 0 : (left > SORT_NT ? SORT_NT : left));
+            const int left = n - r * NT;
+            nsamp += (unsigned)(left < 0 ? 0 : (left > NT ? NT : left));
         }
     }
 #pragma unroll
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         __syncthreads();
         unsigned ex = incl - sum;
 #pragma unroll
-        for (int k = 0; k < SORT_NW; k++) ex += k < w ? red[k] : 0u;
+        for (int k = 0; k < NW; k++) ex += k < w ? red[k] : 0u;
         auto entry = [&](unsigned s, unsigned cb) {
             uint32_t e = s & R3_SMASK;
             if ((s & 3u) + cb > (unsigned)R3_WIN) e |= R3_LONG;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     for (unsigned bi = 0; bi < nbig; bi++) {
         const uint32_t s = misc[2 + 2 * bi];
         const uint32_t k0 = slot[s];
-        for (int i = tid; i < NWORDS; i += SORT_NT) bitmap[i] = 0u;
+        for (int i = tid; i < NWORDS; i += NT) bitmap[i] = 0u;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (VEC && stage && svec) {
 #pragma unroll
         for (int q = 0; q < ITEMS / 4; q++) {
-            const unsigned e0 = (unsigned)(q * SORT_NT + tid) * 4u;
+            const unsigned e0 = (unsigned)(q * NT + tid) * 4u;
             sv[q] = *reinterpret_cast<const float4*>(ssrt + (e0 < ns ? e0 : 0u));
         }
     }
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (tid == 0) a.flags[col] = 1;
         return;
     }
-    for (uint32_t i = tid; i < qn; i += SORT_NT) {
+    for (uint32_t i = tid; i < qn; i += NT) {
         const uint32_t k = qkey[i], w0p = qwin[i];
         const uint4* wp = reinterpret_cast<const uint4*>(slot + w0p);
         uint32_t lt = 0u, le = 0u;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (tid == 0) a.flags[col] = 1;
         return;
     }
-    for (uint32_t t = tid; t < tn; t += SORT_NT) {
+    for (uint32_t t = tid; t < tn; t += NT) {
         const uint32_t i = tlist[t], k = qkey[i], pix = qpix[i];
         uint32_t before = 0u;
         for (uint32_t u = 0; u < tn; u++) {
@@ -496,11 +499,11 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (VEC && svec) {
 #pragma unroll
             for (int q = 0; q < ITEMS / 4; q++) {
-                const unsigned e0 = (unsigned)(q * SORT_NT + tid) * 4u;
+                const unsigned e0 = (unsigned)(q * NT + tid) * 4u;
                 if (e0 < ns) *reinterpret_cast<float4*>(val + e0) = sv[q];
             }
         } else {
-            for (unsigned e = tid; e < ns; e += SORT_NT) val[e] = ssrt[e];
+            for (unsigned e = tid; e < ns; e += NT) val[e] = ssrt[e];
         }
     }
 #pragma unroll
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (VEC && a.out_vec) {
 #pragma unroll
         for (int q = 0; q < ITEMS / 4; q++) {
-            const int e0 = (q * SORT_NT + tid) * 4;
+            const int e0 = (q * NT + tid) * 4;
             if (e0 < n) *reinterpret_cast<float4*>(o + e0) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         }
     } else {
@@ -532,15 +535,15 @@ __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
     SORT_PROBE(10);
 }
 
-template <int ITEMS>
+template <int ITEMS, int NT>
 static int launch_rank_match3_items(SortArgs a, int ncols, hipStream_t st) {
     const bool in_vec = ITEMS >= 4 && ITEMS % 4 == 0 && a.n % 4 == 0 && a.ld % 4 == 0 && a.ss % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
     a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
-    const size_t lds = R3<ITEMS>::LDS;
+    const size_t lds = R3<ITEMS, NT>::LDS;
     hipError_t e;
     if (in_vec) {
-        auto kern = rank_match3_kernel<ITEMS, (ITEMS >= 4 && ITEMS % 4 == 0)>;
+        auto kern = rank_match3_kernel<ITEMS, (ITEMS >= 4 && ITEMS % 4 == 0), NT>;
         static DeviceOnce once;
         bool& attr = *once.slot();
         if (!attr) {
@@ -548,9 +551,9 @@ static int launch_rank_match3_items(SortArgs a, int ncols, hipStream_t st) {
             if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return OPTEX_E_LAUNCH; }
             attr = true;
         }
-        hipLaunchKernelGGL(kern, dim3(ncols), dim3(SORT_NT), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(ncols), dim3(NT), lds, st, a);
     } else {
-        auto kern = rank_match3_kernel<ITEMS, false>;
+        auto kern = rank_match3_kernel<ITEMS, false, NT>;
         static DeviceOnce once;
         bool& attr = *once.slot();
         if (!attr) {
@@ -558,34 +561,37 @@ static int launch_rank_match3_items(SortArgs a, int ncols, hipStream_t st) {
             if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return OPTEX_E_LAUNCH; }
             attr = true;
         }
-        hipLaunchKernelGGL(kern, dim3(ncols), dim3(SORT_NT), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(ncols), dim3(NT), lds, st, a);
     }
     return check_launch("rank_match3_kernel");
 }
 
-// called by launch_sort_items<ITEMS, SORT_MATCH> (sort.hip) with flags cleared and the prof scope open.  The keys per thread
-// are chosen here, as few as hold the column: registers past the end of a column still cost their instructions, so a
-// 12544-key column runs 13 keys per thread (scalar loads) rather than 16 (16-byte loads, 23 % of the slots empty).
+// 9 .. 16 keys per thread on NT threads
+template <int NT>
+static int launch_rank_match3_nt(int need, const SortArgs& a, int ncols, hipStream_t st) {
+    switch (need) {
+        case 9: return launch_rank_match3_items<9, NT>(a, ncols, st);
+        case 10: return launch_rank_match3_items<10, NT>(a, ncols, st);
+        case 11: return launch_rank_match3_items<11, NT>(a, ncols, st);
+        case 12: return launch_rank_match3_items<12, NT>(a, ncols, st);
+        case 13: return launch_rank_match3_items<13, NT>(a, ncols, st);
+        case 14: return launch_rank_match3_items<14, NT>(a, ncols, st);
+        case 15: return launch_rank_match3_items<15, NT>(a, ncols, st);
+        default: return launch_rank_match3_items<16, NT>(a, ncols, st);
+    }
+}
+
+// called by launch_sort_items<ITEMS, SORT_MATCH> (sort.hip) with flags cleared and the prof scope open.  Workgroup size and
+// keys per thread are chosen here: 9 .. 16 keys per thread, as few as hold the column (registers past the end of a column
+// still cost their instructions: a 12544-key column runs 13 keys on 1024 threads, not 16), on 256 / 512 / 1024 threads for
+// columns up to 4096 / 8192 / 16384 keys (smaller workgroups = more columns resident per CU for the short ones).
 int launch_rank_match3(int items, const SortArgs& a, int ncols, hipStream_t st) {
     (void)items;
-    const int need = (int)((a.n + SORT_NT - 1) / SORT_NT);
-    switch (need < 2 ? 2 : need) {
-        case 2: return launch_rank_match3_items<2>(a, ncols, st);
-        case 3: return launch_rank_match3_items<3>(a, ncols, st);
-        case 4: return launch_rank_match3_items<4>(a, ncols, st);
-        case 5: return launch_rank_match3_items<5>(a, ncols, st);
-        case 6: return launch_rank_match3_items<6>(a, ncols, st);
-        case 7: return launch_rank_match3_items<7>(a, ncols, st);
-        case 8: return launch_rank_match3_items<8>(a, ncols, st);
-        case 9: return launch_rank_match3_items<9>(a, ncols, st);
-        case 10: return launch_rank_match3_items<10>(a, ncols, st);
-        case 11: return launch_rank_match3_items<11>(a, ncols, st);
-        case 12: return launch_rank_match3_items<12>(a, ncols, st);
-        case 13: return launch_rank_match3_items<13>(a, ncols, st);
-        case 14: return launch_rank_match3_items<14>(a, ncols, st);
-        case 15: return launch_rank_match3_items<15>(a, ncols, st);
-        default: return launch_rank_match3_items<16>(a, ncols, st);
-    }
+    const long n = a.n;
+    if (n <= 2048) return launch_rank_match3_items<2, SORT_NT>(a, ncols, st);
+    if (n <= 4096) return launch_rank_match3_nt<256>((int)((n + 255) / 256), a, ncols, st);
+    if (n <= 8192) return launch_rank_match3_nt<512>((int)((n + 511) / 512), a, ncols, st);
+    return launch_rank_match3_nt<1024>((int)((n + 1023) / 1024), a, ncols, st);
 }
 
 }  // namespace optex

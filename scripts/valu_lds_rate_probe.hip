@@ -1,0 +1,286 @@
+// Diagnostic: issue cost of the instructions the sort kernels are made of, on gfx950, at the occupancy they run at
+// (8 waves per SIMD).  For each instruction kind a kernel issues REPS x 64 of them per wave; cycles per wave-instruction
+// per SIMD = elapsed x clock x 1024 SIMDs / (waves x REPS x 64).  The clock is taken from hipDeviceProp (the ratios
+// between kinds are what matters).   hipcc --offload-arch=gfx950 -O3 scripts/valu_lds_rate_probe.hip -o /tmp/probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int REPS = 2000;
+
+#define BODY8(INS) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)
+#define BODY64(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS)
+
+#define VALU_KERNEL(NAME, ASMSTR, PER)                                                              \
+    __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed) {                     \
+        unsigned a[8];                                                                              \
+        for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 7 + i + seed;                              \
+        unsigned b = seed + 3, c = threadIdx.x | 1;                                                 \
+        for (int r = 0; r < REPS; r++) {                                                            \
+            _Pragma("unroll") for (int u = 0; u < 8; u++) {                                         \
+                asm volatile(ASMSTR : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]),   \
+                             "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c) : "vcc");          \
+            }                                                                                       \
+        }                                                                                           \
+        unsigned s = 0;                                                                             \
+        for (int i = 0; i < 8; i++) s += a[i];                                                      \
+        if (s == 0x12345678u) out[threadIdx.x] = s;                                                 \
+    }                                                                                               \
+    static const int NAME##_per = PER;
+
+// 8 instructions on 8 independent accumulators per asm block; the block is repeated 8 x REPS times
+#define I8(OP) OP " %0, %0, %8\n\t" OP " %1, %1, %8\n\t" OP " %2, %2, %8\n\t" OP " %3, %3, %8\n\t" \
+               OP " %4, %4, %8\n\t" OP " %5, %5, %8\n\t" OP " %6, %6, %8\n\t" OP " %7, %7, %8"
+VALU_KERNEL(k_add_u32, I8("v_add_u32"), 8)
+VALU_KERNEL(k_and_b32, I8("v_and_b32"), 8)
+VALU_KERNEL(k_min_u32, I8("v_min_u32"), 8)
+VALU_KERNEL(k_mul_f32, I8("v_mul_f32"), 8)
+VALU_KERNEL(k_lshlrev, I8("v_lshlrev_b32"), 8)
+VALU_KERNEL(k_mul_lo_u32, I8("v_mul_lo_u32"), 8)
+#define I8_3(OP) OP " %0, %0, %8, %9\n\t" OP " %1, %1, %8, %9\n\t" OP " %2, %2, %8, %9\n\t" OP " %3, %3, %8, %9\n\t" \
+                 OP " %4, %4, %8, %9\n\t" OP " %5, %5, %8, %9\n\t" OP " %6, %6, %8, %9\n\t" OP " %7, %7, %8, %9"
+VALU_KERNEL(k_fma_f32, I8_3("v_fma_f32"), 8)
+VALU_KERNEL(k_lshl_add, I8_3("v_lshl_add_u32"), 8)
+VALU_KERNEL(k_add3, I8_3("v_add3_u32"), 8)
+VALU_KERNEL(k_bfe, I8_3("v_bfe_u32"), 8)
+VALU_KERNEL(k_mad_u24, I8_3("v_mad_u32_u24"), 8)
+VALU_KERNEL(k_med3, I8_3("v_med3_u32"), 8)
+#define I8_CVT(OP) OP " %0, %0\n\t" OP " %1, %1\n\t" OP " %2, %2\n\t" OP " %3, %3\n\t" OP " %4, %4\n\t" OP " %5, %5\n\t" \
+                   OP " %6, %6\n\t" OP " %7, %7"
+VALU_KERNEL(k_cvt_i32_f32, I8_CVT("v_cvt_i32_f32"), 8)
+VALU_KERNEL(k_cvt_f32_u32, I8_CVT("v_cvt_f32_u32"), 8)
+VALU_KERNEL(k_mov, I8_CVT("v_mov_b32"), 8)
+// compare + add-with-carry pairs (the sort kernel's counting idiom): 8 pairs = 16 instructions
+#define P(N) "v_cmp_lt_u32 vcc, %" #N ", %8\n\tv_addc_co_u32 %" #N ", vcc, 0, %" #N ", vcc\n\t"
+VALU_KERNEL(k_cmp_addc, P(0) P(1) P(2) P(3) P(4) P(5) P(6) "v_cmp_lt_u32 vcc, %7, %8\n\tv_addc_co_u32 %7, vcc, 0, %7, vcc", 16)
+#define Q(N) "v_cmp_lt_u32 vcc, %" #N ", %8\n\tv_cndmask_b32 %" #N ", %" #N ", %9, vcc\n\t"
+VALU_KERNEL(k_cmp_cndmask, Q(0) Q(1) Q(2) Q(3) Q(4) Q(5) Q(6) "v_cmp_lt_u32 vcc, %7, %8\n\tv_cndmask_b32 %7, %7, %9, vcc", 16)
+#define S(N) "v_sub_co_u32 %" #N ", vcc, %" #N ", %8\n\t"
+VALU_KERNEL(k_sub_co, S(0) S(1) S(2) S(3) S(4) S(5) S(6) "v_sub_co_u32 %7, vcc, %7, %8", 8)
+
+// packed: 4 instructions on 4 register pairs
+__global__ __launch_bounds__(256) void k_pk_fma_f32(unsigned* out, unsigned seed) {
+    double a[4];
+    for (int i = 0; i < 4; i++) a[i] = (double)(threadIdx.x + i + seed);
+    double b = 1.0000001, c = 0.5;
+    for (int r = 0; r < REPS; r++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n\tv_pk_fma_f32 %1, %1, %4, %5\n\tv_pk_fma_f32 %2, %2, %4, %5\n\t"
+                         "v_pk_fma_f32 %3, %3, %4, %5"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(b), "v"(c));
+        }
+    }
+    double s = a[0] + a[1] + a[2] + a[3];
+    if (s == 1.2345) out[threadIdx.x] = 1;
+}
+__global__ __launch_bounds__(256) void k_fma_f64(unsigned* out, unsigned seed) {
+    double a[4];
+    for (int i = 0; i < 4; i++) a[i] = (double)(threadIdx.x + i + seed);
+    double b = 1.0000001, c = 0.5;
+    for (int r = 0; r < REPS; r++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\t"
+                         "v_fma_f64 %3, %3, %4, %5"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(b), "v"(c));
+        }
+    }
+    double s = a[0] + a[1] + a[2] + a[3];
+    if (s == 1.2345) out[threadIdx.x] = 1;
+}
+// the quantile index of the sort kernels: u32 -> f64, multiply, fma, f64 -> u32 (4 instructions per element)
+__global__ __launch_bounds__(256) void k_quantile_f64(unsigned* out, unsigned seed) {
+    unsigned a[4];
+    for (int i = 0; i < 4; i++) a[i] = threadIdx.x + i + seed;
+    double b = 1.0000001, c = 0.5;
+    for (int r = 0; r < REPS; r++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            double t0, t1, t2, t3;
+            asm volatile("v_cvt_f64_u32 %4, %0\n\tv_cvt_f64_u32 %5, %1\n\tv_cvt_f64_u32 %6, %2\n\tv_cvt_f64_u32 %7, %3\n\t"
+                         "v_mul_f64 %4, %4, %8\n\tv_mul_f64 %5, %5, %8\n\tv_mul_f64 %6, %6, %8\n\tv_mul_f64 %7, %7, %8\n\t"
+                         "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9\n\t"
+                         "v_cvt_u32_f64 %0, %4\n\tv_cvt_u32_f64 %1, %5\n\tv_cvt_u32_f64 %2, %6\n\tv_cvt_u32_f64 %3, %7"
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                         : "v"(b), "v"(c));
+        }
+    }
+    unsigned s = a[0] + a[1] + a[2] + a[3];
+    if (s == 0x12345678u) out[threadIdx.x] = 1;
+}
+__global__ __launch_bounds__(256) void k_pk_add_u16(unsigned* out, unsigned seed) {
+    unsigned a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 7 + i + seed;
+    unsigned b = seed + 3;
+    for (int r = 0; r < REPS; r++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            asm volatile(I8("v_pk_sub_u16") : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]),
+                         "+v"(a[6]), "+v"(a[7]) : "v"(b));
+        }
+    }
+    unsigned s = 0;
+    for (int i = 0; i < 8; i++) s += a[i];
+    if (s == 0x12345678u) out[threadIdx.x] = s;
+}
+
+// ---- LDS: 64 KiB of LDS per 256-thread block would cap occupancy; use 16 KiB per block (8 blocks per CU = 8 waves/SIMD)
+enum { L_RD32, L_RD64, L_RD128, L_RD128X2, L_WR32, L_ATOM_RTN, L_ATOM_NORTN, L_RD32_SEQ, L_RD128_SEQ, L_RD_U16, L_BPERM };
+template <int KIND>
+__global__ __launch_bounds__(256) void k_lds(unsigned* out, unsigned seed, int reps) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i * 2654435761u;
+    __syncthreads();
+    unsigned x = (threadIdx.x * 2654435761u + seed) ^ (blockIdx.x * 40503u);
+    unsigned acc = 0;
+    for (int r = 0; r < reps; r++) {
+        unsigned addr[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {  // cheap LCG: the address stream is random and independent of the loaded data
+            x = x * 1664525u + 1013904223u;
+            addr[j] = x >> 20;  // 12 bits
+        }
+        if (KIND == L_RD32) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += lds[addr[j]];
+        } else if (KIND == L_RD32_SEQ) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += lds[(threadIdx.x + 256 * j + r) & 4095];
+        } else if (KIND == L_RD_U16) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += reinterpret_cast<unsigned short*>(lds)[addr[j] * 2 + (j & 1)];
+        } else if (KIND == L_RD64) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint2 v = *reinterpret_cast<uint2*>(lds + (addr[j] & ~1u));
+                acc += v.x ^ v.y;
+            }
+        } else if (KIND == L_RD128) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint4 v = *reinterpret_cast<uint4*>(lds + (addr[j] & ~3u));
+                acc += v.x ^ v.y ^ v.z ^ v.w;
+            }
+        } else if (KIND == L_RD128_SEQ) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint4 v = *reinterpret_cast<uint4*>(lds + ((threadIdx.x * 4 + 1024 * j + 4 * r) & 4095));
+                acc += v.x ^ v.y ^ v.z ^ v.w;
+            }
+        } else if (KIND == L_RD128X2) {  // 8-slot aligned-by-4 windows: two 16-byte reads at consecutive addresses (4 windows)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned a0 = (addr[j] & ~3u) & 4087u;
+                const uint4 v = *reinterpret_cast<uint4*>(lds + a0);
+                const uint4 w = *reinterpret_cast<uint4*>(lds + a0 + 4);
+                acc += v.x ^ v.y ^ v.z ^ v.w ^ w.x ^ w.y ^ w.z ^ w.w;
+            }
+        } else if (KIND == L_WR32) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) lds[addr[j]] = x + j;
+        } else if (KIND == L_ATOM_RTN) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += atomicAdd(&lds[addr[j]], 1u);
+        } else if (KIND == L_ATOM_NORTN) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) atomicAdd(&lds[addr[j]], 1u);
+        } else if (KIND == L_BPERM) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += (unsigned)__builtin_amdgcn_ds_bpermute((int)(addr[j] << 2), (int)(x + j));
+        }
+    }
+    __syncthreads();
+    if (acc == 0x12345678u || lds[threadIdx.x] == 0x9abcdef0u) out[threadIdx.x] = acc;
+}
+
+template <typename F>
+static double time_ms(F launch) {
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    launch();
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0));
+    for (int i = 0; i < 3; i++) launch();
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / 3.0;
+}
+
+int main() {
+    hipDeviceProp_t p;
+    CHK(hipGetDeviceProperties(&p, 0));
+    const double clk = p.clockRate * 1e3;  // Hz
+    const int cus = p.multiProcessorCount;
+    printf("device %s, %d CUs, clock %.0f MHz\n", p.name, cus, clk / 1e6);
+    unsigned* out;
+    CHK(hipMalloc(&out, 4096));
+    const int blocks = cus * 8;  // 8 blocks of 4 waves per CU = 8 waves per SIMD
+#define RUN_VALU(NAME, NINS)                                                                                     \
+    {                                                                                                            \
+        const double ms = time_ms([&] { hipLaunchKernelGGL(NAME, dim3(blocks), dim3(256), 0, 0, out, 1u); });     \
+        const double inst = (double)blocks * 4 * REPS * 8.0 * NINS;                                              \
+        printf("%-16s %8.3f ms  %6.2f cycles per wave-instruction per SIMD\n", #NAME, ms,                         \
+               ms * 1e-3 * clk * (cus * 4) / inst);                                                              \
+    }
+    RUN_VALU(k_mov, 8)
+    RUN_VALU(k_add_u32, 8)
+    RUN_VALU(k_and_b32, 8)
+    RUN_VALU(k_min_u32, 8)
+    RUN_VALU(k_lshlrev, 8)
+    RUN_VALU(k_mul_f32, 8)
+    RUN_VALU(k_fma_f32, 8)
+    RUN_VALU(k_lshl_add, 8)
+    RUN_VALU(k_add3, 8)
+    RUN_VALU(k_bfe, 8)
+    RUN_VALU(k_med3, 8)
+    RUN_VALU(k_mad_u24, 8)
+    RUN_VALU(k_mul_lo_u32, 8)
+    RUN_VALU(k_cvt_i32_f32, 8)
+    RUN_VALU(k_cvt_f32_u32, 8)
+    RUN_VALU(k_cmp_addc, 16)
+    RUN_VALU(k_cmp_cndmask, 16)
+    RUN_VALU(k_sub_co, 8)
+    RUN_VALU(k_pk_add_u16, 8)
+    {
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_pk_fma_f32, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+        const double inst = (double)blocks * 4 * REPS * 16.0 * 4;
+        printf("%-16s %8.3f ms  %6.2f cycles per wave-instruction per SIMD\n", "k_pk_fma_f32", ms, ms * 1e-3 * clk * (cus * 4) / inst);
+    }
+    {
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_fma_f64, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+        const double inst = (double)blocks * 4 * REPS * 16.0 * 4;
+        printf("%-16s %8.3f ms  %6.2f cycles per wave-instruction per SIMD\n", "k_fma_f64", ms, ms * 1e-3 * clk * (cus * 4) / inst);
+    }
+    {
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_quantile_f64, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+        const double inst = (double)blocks * 4 * REPS * 16.0 * 16;
+        printf("%-16s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (cvt, mul, fma, cvt)\n", "k_quantile_f64", ms, ms * 1e-3 * clk * (cus * 4) / inst);
+    }
+    const int lreps = 1000;
+#define RUN_LDS(KIND, NOPS)                                                                                            \
+    {                                                                                                                  \
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_lds<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1u, lreps); }); \
+        const double inst = (double)blocks * 4 * lreps * (double)NOPS;                                                 \
+        printf("%-16s %8.3f ms  %6.2f cycles per wave-instruction per CU (incl. 8 LCG steps of 2 VALU per rep)\n", #KIND, ms, \
+               ms * 1e-3 * clk * cus / inst);                                                                          \
+    }
+    RUN_LDS(L_RD32_SEQ, 8)
+    RUN_LDS(L_RD32, 8)
+    RUN_LDS(L_RD_U16, 8)
+    RUN_LDS(L_RD64, 8)
+    RUN_LDS(L_RD128_SEQ, 8)
+    RUN_LDS(L_RD128, 8)
+    RUN_LDS(L_RD128X2, 8)
+    RUN_LDS(L_WR32, 8)
+    RUN_LDS(L_ATOM_RTN, 8)
+    RUN_LDS(L_ATOM_NORTN, 8)
+    RUN_LDS(L_BPERM, 8)
+    return 0;
+}

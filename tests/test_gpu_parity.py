@@ -242,15 +242,16 @@ def test_sort_match_vs_oracle_bit_exact(dev, S, Ss, C, nt, ns):
         assert biteq(out[k], orc.sort_match(t[k], s[k if Ss > 1 else 0]))
 
 
-@pytest.mark.parametrize("k", list(range(2, 17)))
-def test_sort_match_every_keys_per_thread_bit_exact(dev, k):
-    """rank_match3_kernel is instantiated for every number of keys per thread from 2 to 16 (a column takes as few as hold
-    it); columns a little shorter than k * 1024 keys — ragged last register, ties and a ReLU-like half-zero column
-    included — against the oracle"""
+@pytest.mark.parametrize("nt_threads,k", [(1024, 2)] + [(t, k) for t in (256, 512, 1024) for k in range(9, 17)])
+def test_sort_match_every_kernel_variant_bit_exact(dev, nt_threads, k):
+    """rank_match3_kernel is instantiated for 9..16 keys per thread on 256 / 512 / 1024 threads (a column takes the smallest
+    workgroup and as few keys per thread as hold it); columns a little shorter than k * threads keys — ragged last
+    register, ties and a ReLU-like half-zero column included — and an n % 4 == 0 column (16-byte load variants where they
+    exist) against the oracle"""
     from optimaltextures_amd import ops
     from optimaltextures_amd.ops import Seg
-    rng = np.random.default_rng(100 + k)
-    nt, ns = 1024 * k - 3 - (k % 3), 1024 * k // 2 + 7
+    rng = np.random.default_rng(100 + k + nt_threads)
+    nt, ns = nt_threads * k - 3 - (k % 3), nt_threads * k // 2 + 7
     t = rng.standard_normal((2, 3, nt)).astype(np.float32)
     s = (rng.standard_normal((1, 3, ns)) * 2 + 1).astype(np.float32)
     t[0, 0] = np.maximum(t[0, 0], 0)
@@ -258,7 +259,7 @@ def test_sort_match_every_keys_per_thread_bit_exact(dev, k):
     out = ops.sort_match_seg(Seg.of(cu(t, dev)), Seg.of(cu(s, dev))).cpu().numpy()
     for i in range(2):
         assert biteq(out[i], orc.sort_match(t[i], s[0]))
-    t4 = np.ascontiguousarray(t[:, :, : 1024 * (k - 1) + 512])   # n % 4 == 0: the 16-byte load variants where they exist
+    t4 = np.ascontiguousarray(t[:, :, : nt_threads * k - 8])
     out = ops.sort_match_seg(Seg.of(cu(t4, dev)), Seg.of(cu(s, dev))).cpu().numpy()
     for i in range(2):
         assert biteq(out[i], orc.sort_match(t4[i], s[0]))
