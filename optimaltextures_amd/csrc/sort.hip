@@ -509,14 +509,14 @@ __global__ __launch_bounds__(SORT_NT) void sort_columns_kernel(SortArgs a) {
 
 // ================================================================================================ host side
 // OPTEX_SORT_PATH=radix forces the general kernel, =rank1 the one-column-per-CU ranking kernel for the match as well,
-// =rank2 the slot-ranked two-per-CU match kernel of sort_rank2.hip instead of the owner-ranked one of sort_rank3.hip
-// (tests, comparisons)
+// =rank2 the slot-ranked two-per-CU match kernel of sort_rank2.hip, =rank3 the integer-key owner-ranked one of
+// sort_rank3.hip instead of the float-domain owner-ranked default of sort_rank4.hip (tests, comparisons)
 static int sort_path_override() {
     static const int v = [] {
         const char* e = getenv("OPTEX_SORT_PATH");
         if (!e) return 0;
         if (e[0] == 'r' && e[1] == 'a' && e[2] == 'd') return 1;
-        if (e[0] == 'r' && e[1] == 'a' && e[2] == 'n' && e[3] == 'k') return e[4] == '1' ? 2 : (e[4] == '2' ? 3 : 0);
+        if (e[0] == 'r' && e[1] == 'a' && e[2] == 'n' && e[3] == 'k') return e[4] == '1' ? 2 : (e[4] == '2' ? 3 : (e[4] == '3' ? 4 : 0));
         return 0;
     }();
     return v;
@@ -558,8 +558,10 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
             ProfScope prof(MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH, st, 0.0, per_elem * (double)a.n * ncols);
             if (MODE == SORT_MATCH && sort_path_override() == 3) {
                 if ((rc = launch_rank_match(ITEMS, a, ncols, st))) return rc;   // slot-ranked, two columns per CU (sort_rank2.hip)
+            } else if (MODE == SORT_MATCH && sort_path_override() == 4) {
+                if ((rc = launch_rank_match3(ITEMS, a, ncols, st))) return rc;  // owner-ranked, integer keys (sort_rank3.hip)
             } else if (MODE == SORT_MATCH && sort_path_override() != 2) {
-                if ((rc = launch_rank_match3(ITEMS, a, ncols, st))) return rc;  // owner-ranked, two columns per CU (sort_rank3.hip)
+                if ((rc = launch_rank_match4(ITEMS, a, ncols, st))) return rc;  // owner-ranked, float domain (sort_rank4.hip)
             } else {
                 hipLaunchKernelGGL(rkern, dim3(ncols), dim3(SORT_NT), rank_lds_bytes<ITEMS>(MODE == SORT_MATCH), st, a);
             }

@@ -103,7 +103,9 @@ int sort_large(int mode, const SortArgs& a, int ncols, void* ws, hipStream_t st)
 
 // two-columns-per-CU match kernel (sort_rank2.hip); items = 2 / 4 / 8 / 12 / 16 keys per thread
 int launch_rank_match(int items, const SortArgs& a, int ncols, hipStream_t st);
-// owner-ranked two-columns-per-CU match kernel (sort_rank3.hip), the default
+// owner-ranked two-columns-per-CU match kernel on integer totalOrder keys (sort_rank3.hip)
 int launch_rank_match3(int items, const SortArgs& a, int ncols, hipStream_t st);
+// owner-ranked match kernel in the float domain, built on 2-cycle VALU instructions (sort_rank4.hip), the default
+int launch_rank_match4(int items, const SortArgs& a, int ncols, hipStream_t st);
 
 }  // namespace optex

@@ -197,6 +197,145 @@ __global__ __launch_bounds__(256) void k_lds(unsigned* out, unsigned seed, int r
     if (acc == 0x12345678u || lds[threadIdx.x] == 0x9abcdef0u) out[threadIdx.x] = acc;
 }
 
+// ---- wave-wide inclusive scan with DPP only (row_shr 1/2/4/8 inside the 16-lane rows, row_bcast 15 / 31 across them)
+__device__ __forceinline__ unsigned wave_incl_scan_dpp(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__global__ void k_dpp_scan(unsigned* out) {
+    const unsigned v = (threadIdx.x * 2654435761u >> 20) + 1u;
+    out[threadIdx.x] = v;
+    out[64 + threadIdx.x] = wave_incl_scan_dpp(v);
+}
+// float min / max butterflies with DPP (row_shr-free: quad_perm, row_half_mirror, row_mirror, row_bcast)
+__global__ void k_dpp_minmax(float* out) {
+    float v = (float)((threadIdx.x * 2654435761u >> 16) & 0xffff) - 30000.f;
+    out[threadIdx.x] = v;
+    float m = v;
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0xb1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x4e, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+    m = fminf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), 0x140, 0xf, 0xf, false)));  // row_mirror
+    // every lane of a row now holds the row minimum; across rows through readlane
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+    out[64 + threadIdx.x] = fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
+// ---- the two counting idioms of the sort kernels as they stand there (dependent chains), 8 slots per block
+__global__ __launch_bounds__(256) void k_count_cmp(unsigned* out, unsigned seed) {
+    unsigned xs[8];
+    for (int i = 0; i < 8; i++) xs[i] = threadIdx.x * 7 + i * 977 + seed;
+    unsigned lt = 0, le = 0, k = threadIdx.x * 13 + seed;
+    for (int r = 0; r < REPS; r++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            asm volatile("v_cmp_lt_u32 vcc, %2, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %2, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_cmp_lt_u32 vcc, %3, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %3, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_cmp_lt_u32 vcc, %4, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %4, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_cmp_lt_u32 vcc, %5, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %5, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_cmp_lt_u32 vcc, %6, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %6, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_cmp_lt_u32 vcc, %7, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %7, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_cmp_lt_u32 vcc, %8, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %8, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_cmp_lt_u32 vcc, %9, %10\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+                "v_cmp_le_u32 vcc, %9, %10\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+                : "+v"(lt), "+v"(le)
+                : "v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]), "v"(xs[4]), "v"(xs[5]), "v"(xs[6]), "v"(xs[7]), "v"(k) : "vcc");
+        }
+    }
+    if (lt + le == 0x12345678u) out[threadIdx.x] = lt;
+}
+template <int NACC>
+__global__ __launch_bounds__(256) void k_count_fma(unsigned* out, unsigned seed) {
+    float xs[8];
+    for (int i = 0; i < 8; i++) xs[i] = (float)(threadIdx.x * 7 + i * 977 + seed);
+    float k = (float)(threadIdx.x * 13 + seed), big = 1.7014118e38f, c16 = 0.0625f;
+    float acc = 524288.f, acc2 = 0.f;
+    for (int r = 0; r < REPS; r++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float t0, t1;
+            if (NACC == 1) {
+                asm volatile("v_sub_f32 %1, %11, %3\n\tv_sub_f32 %2, %11, %4\n\tv_fma_f32 %1, %1, %12, %13 clamp\n\tv_fma_f32 %2, %2, %12, %13 clamp\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_sub_f32 %1, %11, %5\n\tv_add_f32 %0, %0, %2\n\tv_sub_f32 %2, %11, %6\n\t"
+                    "v_fma_f32 %1, %1, %12, %13 clamp\n\tv_fma_f32 %2, %2, %12, %13 clamp\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_sub_f32 %1, %11, %7\n\tv_add_f32 %0, %0, %2\n\tv_sub_f32 %2, %11, %8\n\t"
+                    "v_fma_f32 %1, %1, %12, %13 clamp\n\tv_fma_f32 %2, %2, %12, %13 clamp\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_sub_f32 %1, %11, %9\n\tv_add_f32 %0, %0, %2\n\tv_sub_f32 %2, %11, %10\n\t"
+                    "v_fma_f32 %1, %1, %12, %13 clamp\n\tv_fma_f32 %2, %2, %12, %13 clamp\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2"
+                    : "+v"(acc), "=&v"(t0), "=&v"(t1)
+                    : "v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]), "v"(xs[4]), "v"(xs[5]), "v"(xs[6]), "v"(xs[7]), "v"(k), "s"(big), "v"(c16));
+            } else {  // same 24 instructions without the clamp modifier and with an SGPR-free fma
+                asm volatile("v_sub_f32 %1, %11, %3\n\tv_sub_f32 %2, %11, %4\n\tv_fma_f32 %1, %1, %12, %13\n\tv_fma_f32 %2, %2, %12, %13\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_sub_f32 %1, %11, %5\n\tv_add_f32 %0, %0, %2\n\tv_sub_f32 %2, %11, %6\n\t"
+                    "v_fma_f32 %1, %1, %12, %13\n\tv_fma_f32 %2, %2, %12, %13\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_sub_f32 %1, %11, %7\n\tv_add_f32 %0, %0, %2\n\tv_sub_f32 %2, %11, %8\n\t"
+                    "v_fma_f32 %1, %1, %12, %13\n\tv_fma_f32 %2, %2, %12, %13\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_sub_f32 %1, %11, %9\n\tv_add_f32 %0, %0, %2\n\tv_sub_f32 %2, %11, %10\n\t"
+                    "v_fma_f32 %1, %1, %12, %13\n\tv_fma_f32 %2, %2, %12, %13\n\t"
+                    "v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2"
+                    : "+v"(acc), "=&v"(t0), "=&v"(t1)
+                    : "v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]), "v"(xs[4]), "v"(xs[5]), "v"(xs[6]), "v"(xs[7]), "v"(k), "v"(big), "v"(c16));
+            }
+        }
+    }
+    if (acc + acc2 == 1.2345f) out[threadIdx.x] = 1;
+}
+
+// ---- the 8-slot window of the sort kernel, three ways (random bases, 4 windows per rep)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const unsigned* lds_cptr;
+enum { W_B64X4, W_READ2X2, W_B128X2 };
+template <int KIND>
+__global__ __launch_bounds__(256) void k_win(unsigned* out, unsigned seed, int reps) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[4096 + 16];
+    for (int i = threadIdx.x; i < 4096 + 16; i += 256) lds[i] = i * 2654435761u;
+    __syncthreads();
+    unsigned x = (threadIdx.x * 2654435761u + seed) ^ (blockIdx.x * 40503u);
+    unsigned acc = 0;
+    for (int r = 0; r < reps; r++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            x = x * 1664525u + 1013904223u;
+            const unsigned idx = x >> 20;  // 12 bits
+            if (KIND == W_B64X4) {
+                lds_cptr p = (lds_cptr)&lds[idx & ~1u];
+                unsigned long long a0, a1, a2, a3;
+                asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\t"
+                             "ds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(p));
+                acc += (unsigned)(a0 ^ a1 ^ a2 ^ a3) ^ (unsigned)((a0 ^ a1 ^ a2 ^ a3) >> 32);
+            } else if (KIND == W_READ2X2) {
+                lds_cptr p = (lds_cptr)&lds[idx & ~1u];
+                v4u a0, a1;
+                asm volatile("ds_read2_b64 %0, %2 offset1:1\n\tds_read2_b64 %1, %2 offset0:2 offset1:3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1) : "v"(p));
+                acc += a0.x ^ a0.y ^ a0.z ^ a0.w ^ a1.x ^ a1.y ^ a1.z ^ a1.w;
+            } else {
+                lds_cptr p = (lds_cptr)&lds[idx & ~3u];
+                v4u a0, a1;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(a1) : "v"(p));
+                acc += a0.x ^ a0.y ^ a0.z ^ a0.w ^ a1.x ^ a1.y ^ a1.z ^ a1.w;
+            }
+        }
+    }
+    if (acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
 template <typename F>
 static double time_ms(F launch) {
     hipEvent_t e0, e1;
@@ -263,6 +402,21 @@ int main() {
         const double inst = (double)blocks * 4 * REPS * 16.0 * 16;
         printf("%-16s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (cvt, mul, fma, cvt)\n", "k_quantile_f64", ms, ms * 1e-3 * clk * (cus * 4) / inst);
     }
+    {
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_count_cmp, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+        const double blk = (double)blocks * 4 * REPS * 4.0;
+        printf("%-16s %8.3f ms  %6.2f cycles per 8-slot block per SIMD (32 instructions: cmp_lt + addc + cmp_le + addc per slot)\n", "k_count_cmp", ms, ms * 1e-3 * clk * (cus * 4) / blk);
+    }
+    {
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_count_fma<1>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+        const double blk = (double)blocks * 4 * REPS * 4.0;
+        printf("%-16s %8.3f ms  %6.2f cycles per 8-slot block per SIMD (24 instructions: sub + fma clamp (SGPR operand) + add per slot)\n", "k_count_fma", ms, ms * 1e-3 * clk * (cus * 4) / blk);
+    }
+    {
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_count_fma<2>, dim3(blocks), dim3(256), 0, 0, out, 1u); });
+        const double blk = (double)blocks * 4 * REPS * 4.0;
+        printf("%-16s %8.3f ms  %6.2f cycles per 8-slot block per SIMD (24 instructions: sub + fma (no clamp, VGPR operands) + add per slot)\n", "k_count_fma_nc", ms, ms * 1e-3 * clk * (cus * 4) / blk);
+    }
     const int lreps = 1000;
 #define RUN_LDS(KIND, NOPS)                                                                                            \
     {                                                                                                                  \
@@ -282,5 +436,35 @@ int main() {
     RUN_LDS(L_ATOM_RTN, 8)
     RUN_LDS(L_ATOM_NORTN, 8)
     RUN_LDS(L_BPERM, 8)
+#define RUN_WIN(KIND)                                                                                                  \
+    {                                                                                                                  \
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_win<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1u, lreps); }); \
+        const double wins = (double)blocks * 4 * lreps * 4.0;                                                          \
+        printf("%-16s %8.3f ms  %6.2f cycles per 8-slot window (wave) per CU (incl. the LCG step and 8 xor)\n", #KIND, ms, \
+               ms * 1e-3 * clk * cus / wins);                                                                          \
+    }
+    RUN_WIN(W_B64X4)
+    RUN_WIN(W_READ2X2)
+    RUN_WIN(W_B128X2)
+    {
+        unsigned* d;
+        CHK(hipMalloc(&d, 128 * 4));
+        hipLaunchKernelGGL(k_dpp_scan, dim3(1), dim3(64), 0, 0, d);
+        unsigned h[128];
+        CHK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        unsigned run = 0;
+        int bad = 0;
+        for (int i = 0; i < 64; i++) { run += h[i]; if (h[64 + i] != run) bad++; }
+        printf("dpp inclusive scan: %s (%d lanes differ)\n", bad ? "WRONG" : "ok", bad);
+        float* f = reinterpret_cast<float*>(d);
+        hipLaunchKernelGGL(k_dpp_minmax, dim3(1), dim3(64), 0, 0, f);
+        float hf[128];
+        CHK(hipMemcpy(hf, f, sizeof(hf), hipMemcpyDeviceToHost));
+        float mn = hf[0];
+        for (int i = 1; i < 64; i++) mn = hf[i] < mn ? hf[i] : mn;
+        bad = 0;
+        for (int i = 0; i < 64; i++) if (hf[64 + i] != mn) bad++;
+        printf("dpp wave minimum: %s (%d lanes differ)\n", bad ? "WRONG" : "ok", bad);
+    }
     return 0;
 }
