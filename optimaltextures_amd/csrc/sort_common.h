@@ -39,6 +39,7 @@ struct SortArgs {
     double inv_2nt;                                           // 1 / (2 * n) for the quantile index
     int ncols;                                                // C * n_seg
     int out_vec;                                              // rank_match_kernel: `out` takes 16-byte stores
+    int stagger;                                              // rank_match4_kernel: workgroups of the first generation (0 = no stagger)
 #ifdef R2_DEBUG
     uint32_t* dbg;                                            // scripts/sort_rank2_debug.hip
 #endif

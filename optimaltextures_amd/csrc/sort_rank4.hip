@@ -197,6 +197,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (threadIdx.x == 0) a.flags[blockIdx.x] = 1;  // never on this toolchain: the radix kernel would take every column
         return;
     }
+    // Two workgroups share a CU.  Launched together they run in lock step — both waiting for their column, then both on
+    // the LDS, then both on the VALU — and leave each unit idle while the other phase lasts.  In the first generation the
+    // workgroup that got the upper half of the LDS sleeps for about half a column (2 cycles per key); its successors keep
+    // the offset.
+    if ((int)blockIdx.x < a.stagger) {
+        uint32_t la;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
+        if ((la & 0xfffu) != 0u)
+            for (int i = 0; i < n; i += 4096) __builtin_amdgcn_s_sleep(127);
+    }
     SORT_PROBE(0);
     // ---- 0. the column (registers past the end hold a copy of a real key: harmless for min / max, and they stay out of
     //         every LDS update below through selects)
@@ -245,10 +255,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const bool bad = !(nf == 0.f) || tz > 0.f;
         if (__any(bad)) hi = __uint_as_float(R4_INF);
     }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        lo = r4_min(lo, __shfl_xor(lo, s));
-        hi = r4_max(hi, __shfl_xor(hi, s));
+    // wave minimum / maximum without LDS round trips: four DPP butterflies inside the 16-lane rows (quad_perm [1,0,3,2],
+    // [2,3,0,1], row_half_mirror, row_mirror), then the four row results through readlane
+    {
+        auto dpp = [](float v, auto ctrl) {
+            return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, false));
+        };
+        lo = r4_min(lo, dpp(lo, std::integral_constant<int, 0xb1>{}));
+        hi = r4_max(hi, dpp(hi, std::integral_constant<int, 0xb1>{}));
+        lo = r4_min(lo, dpp(lo, std::integral_constant<int, 0x4e>{}));
+        hi = r4_max(hi, dpp(hi, std::integral_constant<int, 0x4e>{}));
+        lo = r4_min(lo, dpp(lo, std::integral_constant<int, 0x141>{}));
+        hi = r4_max(hi, dpp(hi, std::integral_constant<int, 0x141>{}));
+        lo = r4_min(lo, dpp(lo, std::integral_constant<int, 0x140>{}));
+        hi = r4_max(hi, dpp(hi, std::integral_constant<int, 0x140>{}));
+        auto rl = [](float v, auto l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), decltype(l)::value)); };
+        lo = r4_min(r4_min(rl(lo, std::integral_constant<int, 0>{}), rl(lo, std::integral_constant<int, 16>{})),
+                    r4_min(rl(lo, std::integral_constant<int, 32>{}), rl(lo, std::integral_constant<int, 48>{})));
+        hi = r4_max(r4_max(rl(hi, std::integral_constant<int, 0>{}), rl(hi, std::integral_constant<int, 16>{})),
+                    r4_max(rl(hi, std::integral_constant<int, 32>{}), rl(hi, std::integral_constant<int, 48>{})));
     }
     if (lane == 0) {
         red[w] = __float_as_uint(lo);
@@ -763,31 +788,71 @@ static int launch_rank_match4_items(SortArgs a, int ncols, hipStream_t st) {
     return check_launch("rank_match4_kernel");
 }
 
-// 9 .. 16 keys per thread on NT threads
-template <int NT>
-static int launch_rank_match4_nt(int need, const SortArgs& a, int ncols, hipStream_t st) {
-    switch (need) {
-        case 9: return launch_rank_match4_items<9, NT>(a, ncols, st);
-        case 10: return launch_rank_match4_items<10, NT>(a, ncols, st);
-        case 11: return launch_rank_match4_items<11, NT>(a, ncols, st);
-        case 12: return launch_rank_match4_items<12, NT>(a, ncols, st);
-        case 13: return launch_rank_match4_items<13, NT>(a, ncols, st);
-        case 14: return launch_rank_match4_items<14, NT>(a, ncols, st);
-        case 15: return launch_rank_match4_items<15, NT>(a, ncols, st);
-        default: return launch_rank_match4_items<16, NT>(a, ncols, st);
-    }
+int device_cu_count();
+
+// OPTEX_SORT_STAGGER=1 switches the first-generation stagger on (measured: +1.3 % at 16384 keys, -1 % at 12544: the
+// workgroups of a CU drift apart by themselves)
+static int stagger_enabled() {
+    static const int v = [] {
+        const char* e = getenv("OPTEX_SORT_STAGGER");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    return v;
 }
 
-// called by launch_sort_items<ITEMS, SORT_MATCH> (sort.hip) with flags cleared and the prof scope open.  Workgroup size and
-// keys per thread are chosen here: 9 .. 16 keys per thread, exactly ceil(n / threads) (the kernel relies on it: only the
-// last register row can be ragged), on 256 / 512 / 1024 threads for columns up to 4096 / 8192 / 16384 keys.
-int launch_rank_match4(int items, const SortArgs& a, int ncols, hipStream_t st) {
+// OPTEX_SORT_EXTRA_NT=0: 6400-key columns on 1024 threads x 7 keys instead of 640 x 10 (measurements)
+static int extra_nt_enabled() {
+    static const int v = [] {
+        const char* e = getenv("OPTEX_SORT_EXTRA_NT");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return v;
+}
+
+int launch_rank_match4(int items, const SortArgs& a0, int ncols, hipStream_t st) {
     (void)items;
+    SortArgs a = a0;
     const long n = a.n;
+    // two 1024-thread workgroups per CU for columns above 8192 keys; the smaller workgroups of shorter columns come four
+    // and eight to a CU and drift apart by themselves
+    a.stagger = (stagger_enabled() && n > 8192 && ncols > 2 * device_cu_count()) ? 2 * device_cu_count() : 0;
+    // Workgroup size and keys per thread, always exactly ceil(n / threads) keys (the kernel relies on it: only the last
+    // register row can be ragged).  Measured at [64, 256, n] (profiles/r02_sort_rank4_shapes.md): a column wants 6 .. 10
+    // keys per thread — shorter register chains, no spills — as long as that leaves the CU its 32 wavefronts: 4096 keys
+    // 227 us on 512 x 8 against 287 us on 256 x 16 and 323 us on 1024 x 4; 8192 keys 486 us on 1024 x 8 against 580 us on
+    // 512 x 16; 5120 keys 287 us on 512 x 10 against 381 us on 1024 x 5.  Above 10240 keys a workgroup cannot have more
+    // threads, and the keys per thread grow to 16.
     if (n <= 2048) return launch_rank_match4_items<2, SORT_NT>(a, ncols, st);
-    if (n <= 4096) return launch_rank_match4_nt<256>((int)((n + 255) / 256), a, ncols, st);
-    if (n <= 8192) return launch_rank_match4_nt<512>((int)((n + 511) / 512), a, ncols, st);
-    return launch_rank_match4_nt<1024>((int)((n + 1023) / 1024), a, ncols, st);
+    if (n <= 2560) {
+        if (n <= 9 * 256) return launch_rank_match4_items<9, 256>(a, ncols, st);
+        return launch_rank_match4_items<10, 256>(a, ncols, st);
+    }
+    if (n <= 5120) {
+        switch ((int)((n + 511) / 512)) {
+            case 6: return launch_rank_match4_items<6, 512>(a, ncols, st);
+            case 7: return launch_rank_match4_items<7, 512>(a, ncols, st);
+            case 8: return launch_rank_match4_items<8, 512>(a, ncols, st);
+            case 9: return launch_rank_match4_items<9, 512>(a, ncols, st);
+            default: return launch_rank_match4_items<10, 512>(a, ncols, st);
+        }
+    }
+    // 6400 keys (a pass size of the 512^2 schedule) fill 640 threads x 10 keys exactly, three workgroups to a CU.  (Tried
+    // and slower: 9216 keys on 576 x 16, three workgroups of nine wavefronts to a CU, 822 us against 573 us on 1024 x 9;
+    // 12544 keys on 896 x 14, 936 us against 826 us on 1024 x 13.)
+    if (n == 10 * 640 && extra_nt_enabled()) return launch_rank_match4_items<10, 640>(a, ncols, st);
+    switch ((int)((n + 1023) / 1024)) {
+        case 6: return launch_rank_match4_items<6, 1024>(a, ncols, st);
+        case 7: return launch_rank_match4_items<7, 1024>(a, ncols, st);
+        case 8: return launch_rank_match4_items<8, 1024>(a, ncols, st);
+        case 9: return launch_rank_match4_items<9, 1024>(a, ncols, st);
+        case 10: return launch_rank_match4_items<10, 1024>(a, ncols, st);
+        case 11: return launch_rank_match4_items<11, 1024>(a, ncols, st);
+        case 12: return launch_rank_match4_items<12, 1024>(a, ncols, st);
+        case 13: return launch_rank_match4_items<13, 1024>(a, ncols, st);
+        case 14: return launch_rank_match4_items<14, 1024>(a, ncols, st);
+        case 15: return launch_rank_match4_items<15, 1024>(a, ncols, st);
+        default: return launch_rank_match4_items<16, 1024>(a, ncols, st);
+    }
 }
 
 }  // namespace optex

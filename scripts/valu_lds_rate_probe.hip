@@ -336,6 +336,17 @@ __global__ __launch_bounds__(256) void k_win(unsigned* out, unsigned seed, int r
     if (acc == 0x12345678u) out[threadIdx.x] = acc;
 }
 
+// what HW_REG_LDS_ALLOC / HW_REG_HW_ID say for two 80 KiB workgroups per CU
+__global__ __launch_bounds__(1024) void k_hwreg(unsigned* out) {
+    extern __shared__ unsigned dyn[];
+    dyn[threadIdx.x] = threadIdx.x;
+    unsigned la, id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+    __builtin_amdgcn_s_sleep(100);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = la; out[2 * blockIdx.x + 1] = id; }
+}
+
 template <typename F>
 static double time_ms(F launch) {
     hipEvent_t e0, e1;
@@ -442,6 +453,20 @@ int main() {
         const double wins = (double)blocks * 4 * lreps * 4.0;                                                          \
         printf("%-16s %8.3f ms  %6.2f cycles per 8-slot window (wave) per CU (incl. the LCG step and 8 xor)\n", #KIND, ms, \
                ms * 1e-3 * clk * cus / wins);                                                                          \
+    }
+    {
+        unsigned* d;
+        const int nb = 1024;
+        CHK(hipMalloc(&d, nb * 8));
+        CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hwreg), hipFuncAttributeMaxDynamicSharedMemorySize, 81776));
+        hipLaunchKernelGGL(k_hwreg, dim3(nb), dim3(1024), 81776, 0, d);
+        std::vector<unsigned> h(nb * 2);
+        CHK(hipMemcpy(h.data(), d, nb * 8, hipMemcpyDeviceToHost));
+        printf("HW_REG_LDS_ALLOC / HW_ID of workgroups 0..7 and 512..515:");
+        for (int i : {0, 1, 2, 3, 4, 5, 6, 7, 512, 513, 514, 515}) printf(" %08x/%08x", h[2 * i], h[2 * i + 1]);
+        int nz = 0;
+        for (int i = 0; i < nb; i++) nz += (h[2 * i] & 0xfff) != 0;
+        printf("\nworkgroups with a non-zero LDS base field: %d of %d\n", nz, nb);
     }
     RUN_WIN(W_B64X4)
     RUN_WIN(W_READ2X2)

@@ -242,12 +242,13 @@ def test_sort_match_vs_oracle_bit_exact(dev, S, Ss, C, nt, ns):
         assert biteq(out[k], orc.sort_match(t[k], s[k if Ss > 1 else 0]))
 
 
-@pytest.mark.parametrize("nt_threads,k", [(1024, 2)] + [(t, k) for t in (256, 512, 1024) for k in range(9, 17)])
+@pytest.mark.parametrize("nt_threads,k", [(1024, 2), (256, 9), (256, 10), (640, 10)] + [(512, k) for k in range(6, 11)] +
+                         [(1024, k) for k in range(6, 17)])
 def test_sort_match_every_kernel_variant_bit_exact(dev, nt_threads, k):
-    """rank_match3_kernel is instantiated for 9..16 keys per thread on 256 / 512 / 1024 threads (a column takes the smallest
-    workgroup and as few keys per thread as hold it); columns a little shorter than k * threads keys — ragged last
-    register, ties and a ReLU-like half-zero column included — and an n % 4 == 0 column (16-byte load variants where they
-    exist) against the oracle"""
+    """rank_match4_kernel is instantiated for 9 / 10 keys per thread on 256 threads, 6..10 on 512, 6..16 on 1024 and 10 on
+    640 (a column takes the workgroup that gives it 6..10 keys per thread, csrc/sort_rank4.hip); columns a little shorter
+    than k * threads keys — ragged last register, ties and a ReLU-like half-zero column included — an n % 4 == 0 column
+    (16-byte load variants where they exist) and a column that fills the registers exactly, against the oracle"""
     from optimaltextures_amd import ops
     from optimaltextures_amd.ops import Seg
     rng = np.random.default_rng(100 + k + nt_threads)
@@ -263,6 +264,29 @@ def test_sort_match_every_kernel_variant_bit_exact(dev, nt_threads, k):
     out = ops.sort_match_seg(Seg.of(cu(t4, dev)), Seg.of(cu(s, dev))).cpu().numpy()
     for i in range(2):
         assert biteq(out[i], orc.sort_match(t4[i], s[0]))
+    tf = np.concatenate([t, t[:, :, : nt_threads * k - nt]], axis=2)   # exactly k * threads keys
+    out = ops.sort_match_seg(Seg.of(cu(tf, dev)), Seg.of(cu(s, dev))).cpu().numpy()
+    for i in range(2):
+        assert biteq(out[i], orc.sort_match(tf[i], s[0]))
+
+
+@pytest.mark.parametrize("nt,ns", [(9216, 9216), (9216, 6912), (12544, 12544), (12544, 9408), (6400, 6400), (6400, 4801)])
+def test_sort_match_pass_sizes_bit_exact(dev, nt, ns):
+    """the pass sizes of the 512^2 schedule that are no power of two (6400 keys run on 640 threads x 10 keys, which they
+    fill exactly — csrc/sort_rank4.hip): ties, a half-zero column, signed zeros, a tie group spread over the column,
+    against the oracle"""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    rng = np.random.default_rng(nt + 3 * ns)
+    t = rng.standard_normal((2, 4, nt)).astype(np.float32)
+    s = (rng.standard_normal((1, 4, ns)) * 2 + 1).astype(np.float32)
+    t[0, 0] = np.maximum(t[0, 0], 0)
+    t[1, 1, ::7] = t[1, 1, 3]
+    t[0, 2, ::5] = np.where(rng.random(t[0, 2, ::5].shape) < 0.5, -0.0, 0.0)
+    t[1, 3, :40] = t[1, 3, 100]
+    out = ops.sort_match_seg(Seg.of(cu(t, dev)), Seg.of(cu(s, dev))).cpu().numpy()
+    for i in range(2):
+        assert biteq(out[i], orc.sort_match(t[i], s[0]))
 
 
 def _ulp_clusters(n, rng):
