@@ -185,13 +185,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const unsigned ns = (unsigned)a.ns;
     const int n = FULL ? CAP : (int)a.n;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // pixel held in register r: 16-byte loads put 4 neighbouring pixels into one thread
-    auto elem = [&](int r) { return VEC ? ((r >> 2) * NT + tid) * 4 + (r & 3) : r * NT + tid; };
+    // VEC: the first 4 * Q registers are Q 16-byte loads (4 neighbouring pixels in one thread), the remaining T = ITEMS % 4
+    // registers are scalar rows behind them (row r starts at pixel r * NT either way)
+    constexpr int Q = VEC ? ITEMS / 4 : 0, T = ITEMS - 4 * Q;
+    // pixel held in register r
+    auto elem = [&](int r) { return r < 4 * Q ? ((r >> 2) * NT + tid) * 4 + (r & 3) : r * NT + tid; };
     // can register r lie past the end of the column?  ITEMS = ceil(n / NT) (the launcher guarantees it for ITEMS > 2):
-    // only the last row — with 16-byte loads the last quad — can be ragged
-    auto ragged = [](int r) { return !FULL && (ITEMS == 2 || (VEC ? r >= ITEMS - 4 : r == ITEMS - 1)); };
+    // only the last row — without scalar rows the last quad — can be ragged
+    auto ragged = [](int r) { return !FULL && (ITEMS == 2 || ((VEC && T == 0) ? r >= ITEMS - 4 : r == ITEMS - 1)); };
     // register r holds a pixel of the column: a compare of tid with a scalar
-    auto valid = [&](int r) { return !ragged(r) || (VEC ? tid < (n >> 2) - (r >> 2) * NT : tid < n - r * NT); };
+    auto valid = [&](int r) { return !ragged(r) || ((VEC && T == 0) ? tid < (n >> 2) - (r >> 2) * NT : tid < n - r * NT); };
 
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) {
         if (threadIdx.x == 0) a.flags[blockIdx.x] = 1;  // never on this toolchain: the radix kernel would take every column
@@ -211,22 +214,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // ---- 0. the column (registers past the end hold a copy of a real key: harmless for min / max, and they stay out of
     //         every LDS update below through selects)
     float x[ITEMS];
-    if (VEC) {
 #pragma unroll
-        for (int q = 0; q < ITEMS / 4; q++) {
-            const int e0 = (q * NT + tid) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(src + (ragged(4 * q) ? (e0 < n ? e0 : 0) : e0));
-            x[4 * q + 0] = v.x;
-            x[(4 * q + 1) % ITEMS] = v.y;
-            x[(4 * q + 2) % ITEMS] = v.z;
-            x[(4 * q + 3) % ITEMS] = v.w;
-        }
-    } else {
+    for (int q = 0; q < Q; q++) {
+        const int e0 = (q * NT + tid) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (ragged(4 * q) ? (e0 < n ? e0 : 0) : e0));
+        x[4 * q + 0] = v.x;
+        x[(4 * q + 1) % ITEMS] = v.y;
+        x[(4 * q + 2) % ITEMS] = v.z;
+        x[(4 * q + 3) % ITEMS] = v.w;
+    }
 #pragma unroll
-        for (int r = 0; r < ITEMS; r++) {
-            const int e = r * NT + tid;
-            x[r] = src[ragged(r) ? (e < n ? e : n - 1) : e];
-        }
+    for (int r = 4 * Q; r < ITEMS; r++) {
+        const int e = r * NT + tid;
+        x[r] = src[ragged(r) ? (e < n ? e : n - 1) : e];
     }
     for (int i = tid; i < K::CNTW; i += NT) cnt[i] = 0u;
     if (tid < RK_COARSE) c1[tid] = 0u;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     //         balances the bucket sizes)
     constexpr int RS = VEC ? 4 : (ITEMS >= 8 ? 4 : 1);
     unsigned nsamp = 0;
-    if (VEC) {
+    if (VEC && T == 0) {
         nsamp = (unsigned)(n + 3) / 4u;
     } else {
 #pragma unroll
@@ -628,12 +628,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // element offsets of step 0 were kept alive, spilled, for the whole kernel)
     int tid9 = tid;
     asm volatile("" : "+v"(tid9));
-    r4_v4f sv[VEC ? ITEMS / 4 : 1];
+    r4_v4f sv[Q > 0 ? Q : 1];
+    float svt[T > 0 ? T : 1];
     if (VEC && stage && svec) {
 #pragma unroll
-        for (int q = 0; q < ITEMS / 4; q++) {
+        for (int q = 0; q < Q; q++) {
             const unsigned e0 = (unsigned)(q * NT + tid9) * 4u;
             sv[q] = *reinterpret_cast<const r4_v4f*>(ssrt + (e0 < ns ? e0 : 0u));
+        }
+#pragma unroll
+        for (int r = 4 * Q; r < ITEMS; r++) {
+            const unsigned e = (unsigned)(r * NT + tid9);
+            svt[r - 4 * Q] = ssrt[e < ns ? e : 0u];
         }
     }
     // ---- 8. queued keys, one per thread, against a 52-slot window (a bucket has at most RK_BIG keys here): buckets wider
@@ -697,9 +703,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (stage) {
         if (VEC && svec) {
 #pragma unroll
-            for (int q = 0; q < ITEMS / 4; q++) {
+            for (int q = 0; q < Q; q++) {
                 const unsigned e0 = (unsigned)(q * NT + tid9) * 4u;
                 if (e0 < ns) R4_LDS(r4_v4f, SLOT_B + (e0 << 2)) = sv[q];
+            }
+#pragma unroll
+            for (int r = 4 * Q; r < ITEMS; r++) {
+                const unsigned e = (unsigned)(r * NT + tid9);
+                if (e < ns) R4_LDS(float, SLOT_B + (e << 2)) = svt[r - 4 * Q];
             }
         } else {
             for (unsigned e = tid; e < ns; e += NT) val[e] = ssrt[e];
@@ -737,16 +748,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     if (VEC && a.out_vec) {
 #pragma unroll
-        for (int q = 0; q < ITEMS / 4; q++) {
+        for (int q = 0; q < Q; q++) {
             const int e0 = (q * NT + tid9) * 4;
             if (!ragged(4 * q) || e0 < n)
                 *reinterpret_cast<float4*>(o + e0) =
                     make_float4(v[4 * q], v[(4 * q + 1) % ITEMS], v[(4 * q + 2) % ITEMS], v[(4 * q + 3) % ITEMS]);
         }
+#pragma unroll
+        for (int r = 4 * Q; r < ITEMS; r++)
+            if (valid(r)) o[r * NT + tid9] = v[r];
     } else {
 #pragma unroll
         for (int r = 0; r < ITEMS; r++)
-            if (valid(r)) o[VEC ? ((r >> 2) * NT + tid9) * 4 + (r & 3) : r * NT + tid9] = v[r];
+            if (valid(r)) o[r < 4 * Q ? ((r >> 2) * NT + tid9) * 4 + (r & 3) : r * NT + tid9] = v[r];
     }
     SORT_PROBE(10);
 }
@@ -765,8 +779,10 @@ static int launch_one4(KernT kern, DeviceOnce& once, size_t lds, const SortArgs&
 
 template <int ITEMS, int NT>
 static int launch_rank_match4_items(SortArgs a, int ncols, hipStream_t st) {
-    constexpr bool CANVEC = ITEMS >= 4 && ITEMS % 4 == 0;
-    const bool in_vec = CANVEC && a.n % 4 == 0 && a.ld % 4 == 0 && a.ss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
+    // 16-byte loads for the first 4 * (ITEMS / 4) registers; without scalar rows behind them the column must end on a quad
+    constexpr bool CANVEC = ITEMS >= 4;
+    const bool in_vec = CANVEC && (ITEMS % 4 != 0 || a.n % 4 == 0) && a.ld % 4 == 0 && a.ss % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
     a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
     const size_t lds = R4<ITEMS, NT>::LDS;
     const bool full = a.n == (long)ITEMS * NT;
