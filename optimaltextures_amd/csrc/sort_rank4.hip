@@ -589,12 +589,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         a2 = R4_LDS(const volatile r4_v2u, off + 16u);
         a3 = R4_LDS(const volatile r4_v2u, off + 24u);
     };
-#ifndef R4_PAIR
-#define R4_PAIR 0
-#endif
-#if R4_PAIR
+    // One workgroup alone on a CU spends 66 cycles per wavefront and key here (LDS 29 + VALU 22 if they did not overlap at
+    // all: profiles/r02_sort_rank4_one_vs_two_workgroups.log): with one window in flight per wavefront the step is bound by
+    // the LDS round trip (16 windows in flight per workgroup), not by a pipe.  A second window in flight per wavefront
+    // helps where the registers are there for it — up to 10 keys per thread (9216 keys 549 -> 521 us, 8192 keys 484 ->
+    // 462 us); beyond that it spills and costs more than it hides (16 keys per thread: 904 -> 917 us).  Starting every
+    // other wavefront half a round late, wave priorities and a first-generation stagger of the two workgroups of a CU
+    // were measured too: no gain.
+    if (ITEMS <= 10) {
 #pragma unroll
-    for (int g = 0; g + 1 < ITEMS; g += 2) {  // two windows in flight
+    for (int g = 0; g + 1 < ITEMS; g += 2) {
         r4_v2u a0, a1, a2, a3, b0, b1, b2, b3;
         wload(g, a0, a1, a2, a3);
         wload(g + 1, b0, b1, b2, b3);
@@ -607,9 +611,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         wload(ITEMS - 1, a0, a1, a2, a3);
         rank_one(ITEMS - 1, a0, a1, a2, a3);
     }
-#else
-    // one window in flight: eight more live registers (a second window) spill under the 64-VGPR budget, and a scratch
-    // round trip costs more than the LDS latency the other seven wavefronts of the SIMD cover anyway
+    } else {
 #pragma unroll
     for (int g = 0; g < ITEMS; g++) {
         r4_v2u a0, a1, a2, a3;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         rank_one(g, a0, a1, a2, a3);
         asm volatile("" ::: "memory");
     }
-#endif
+    }
     asm volatile("" ::: "memory");
     SORT_PROBE(7);
     // the sorted source column on its way into registers while the queue is worked off (the key registers are dead)
@@ -767,6 +769,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
 template <typename KernT>
 static int launch_one4(KernT kern, DeviceOnce& once, size_t lds, const SortArgs& a, int ncols, int nt, hipStream_t st) {
+#ifdef OPTEX_SORT_PROBE
+    if (const char* e = getenv("OPTEX_SORT_LDS_PAD")) lds += (size_t)atol(e);  // fewer workgroups per CU (scripts/sort_rank_probe.hip)
+#endif
     bool& attr = *once.slot();
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
