@@ -95,6 +95,9 @@ def main(argv=None):
         if len(styles) > 1:
             assert styles[0].shape == styles[1].shape, "Style images must have the same shape"
         content = maybe_load_content(content_file, size=args.size, device=device, memory_format=memory_format)
+        if world > 1 and args.independent and args.batch < world:
+            # a rank with an empty shard would hand a (0, 3, H, W) pastiche to the kernels and abort the whole job
+            raise SystemExit(f"--independent over {world} ranks needs --batch >= {world} (got {args.batch})")
         lo, hi = otdist.shard_range(args.batch, rank, world) if (world > 1 and args.independent) else (0, args.batch)
         shape = content.shape if content is not None else (hi - lo, 3, args.size, args.size)
         pastiche = torch.rand(shape).to(device=device, memory_format=memory_format)

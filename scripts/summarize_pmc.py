@@ -19,7 +19,7 @@ import re
 CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"),
             ("col_hist_kernel", "col_hist"), ("col_minmax_kernel", "col_minmax"), ("cdf_lut_kernel", "cdf_lut"),
             ("glue_kernel", "vgg_glue"), ("glue_nhwc_kernel", "vgg_glue"), ("glue_transpose", "vgg_glue"),
-            ("rank_match_kernel", "sort_match"), ("rank_match3_kernel", "sort_match"), ("rank_columns_kernel", "sort_rank"),
+            ("rank_match_kernel", "sort_match"), ("rank_match3_kernel", "sort_match"), ("rank_match4_kernel", "sort_match"), ("rank_columns_kernel", "sort_rank"),
             ("gram128_kernel", "gram"), ("minmax_from_parts_kernel", "col_minmax"), ("mean_from_parts_kernel", "col_mean"),
             ("chol_inv_kernel", "chol_inv"), ("ns_init_kernel", "ns_init"), ("cov_finalize_kernel", "cov_finalize"), ("sort_columns_kernel", "sort_radix"), ("gram_kernel", "gram"),
             ("col_mean_kernel", "col_mean"), ("householder_apply", "householder")]
