@@ -37,7 +37,7 @@
 namespace optex {
 
 constexpr uint32_t R4_TAG = 0x80000000u;   // ba: rank pending in queue entry (low bits)
-constexpr uint32_t R4_DONE = 0x40000000u;  // ba: rank already final (all-equal big bucket)
+// start entry with BIGF set and LONG clear: rank already final (all-equal big bucket; the scan sets both for a big bucket)
 constexpr uint32_t R4_LONG = 0x8000u;      // start entry: bucket does not fit the aligned 8-slot window
 constexpr uint32_t R4_BIGF = 0x4000u;      // start entry: bucket larger than RK_BIG
 constexpr uint32_t R4_SMASK = 0x3fffu;     // start entry: first slot of the bucket (mod 16384)
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
-            if (valid(r) && (ba[r] & (R4_DONE | R4_BIGF)) == R4_BIGF && (ba[r] & R4_SMASK) == (s & R4_SMASK)) {
+            if (valid(r) && (ba[r] & (R4_LONG | R4_BIGF)) == (R4_LONG | R4_BIGF) && (ba[r] & R4_SMASK) == (s & R4_SMASK)) {
                 if (__float_as_uint(x[r]) != k0) misc[1] = 1u;
                 const uint32_t idx = (uint32_t)elem(r);
                 atomicOr(&bitmap[idx >> 5], 1u << (idx & 31u));
@@ -539,10 +539,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
-            const bool mine = valid(r) && (ba[r] & (R4_DONE | R4_BIGF)) == R4_BIGF && (ba[r] & R4_SMASK) == (s & R4_SMASK);
+            const bool mine = valid(r) && (ba[r] & (R4_LONG | R4_BIGF)) == (R4_LONG | R4_BIGF) && (ba[r] & R4_SMASK) == (s & R4_SMASK);
             const uint32_t idx = (uint32_t)(valid(r) ? elem(r) : 0);
             const uint32_t rk = s + bpre[idx >> 5] + (uint32_t)__popc(bitmap[idx >> 5] & ((1u << (idx & 31u)) - 1u));
-            ba[r] = mine ? (R4_DONE | rk) : ba[r];
+            ba[r] = mine ? (R4_BIGF | (rk & R4_SMASK)) : ba[r];
             asm volatile("" ::: "memory");
         }
         __syncthreads();
@@ -553,10 +553,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     //         bucket.  ba[r] becomes the rank (or R4_TAG | queue entry).
     const float big = 1.7014118e38f;  // 2^127
     const float c16 = 0.0625f;
-    // Common case in two 4-cycle instructions (v_bfe, one v_cmp): the start entry's LONG / DONE bits and the "exactly one
+    // The 16-bit start entries are packed two to a register for this step: with the keys (16), the results (16, filling
+    // up as the entries drain) and two windows in flight (16) the unpacked entries (16 more) do not fit the 64 VGPRs.
+    uint32_t pe[(ITEMS + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < (ITEMS + 1) / 2; k++) pe[k] = (2 * k + 1 < ITEMS) ? (ba[2 * k] & 0xffffu) | (ba[2 * k + 1] << 16) : ba[2 * k];
+#pragma unroll
+    for (int k = 0; k < (ITEMS + 1) / 2; k++) asm volatile("" : "+v"(pe[k]));
+    // Common case in two 4-cycle instructions (v_bfe, one v_cmp): the start entry's LONG / BIG bits and the "exactly one
     // equal slot (myself)" test are merged into one word that is zero for a key ranked by its window.
+    auto entry_of = [&](int r) { return (r & 1) ? pe[r >> 1] >> 16 : (pe[r >> 1] & 0xffffu); };
     auto rank_one = [&](int r, const r4_v2u& a0, const r4_v2u& a1, const r4_v2u& a2, const r4_v2u& a3) {
-        const uint32_t e = ba[r];
+        const uint32_t e = entry_of(r);
         const uint32_t w0p = e & (R4_SMASK & ~1u);
         float acc = 524288.f;  // 2^19: ulp 1/16
         r4_window(acc, a0, a1, a2, a3, x[r], big, c16);
@@ -564,9 +572,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         uint32_t res = w0p + __builtin_amdgcn_ubfe(bits, 4, 4);
         // (bits - 1) & 15 != 0: another slot holds the same key (the pixels decide) -> the queue, like a bucket wider
         // than the window
-        const uint32_t special = ((bits - 1u) & 15u) | (e & (R4_LONG | R4_DONE));
+        const uint32_t special = ((bits - 1u) & 15u) | (e & (R4_LONG | R4_BIGF));
         if (special != 0u) {
-            if ((e & R4_DONE) != 0u) {
+            if ((e & (R4_LONG | R4_BIGF)) == R4_BIGF) {  // final already
                 res = e & R4_SMASK;
             } else if (!ragged(r) || valid(r)) {
                 const uint32_t qi = atomicAdd(&misc[20], 1u);
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // four single 8-byte reads per window (volatile: merged into ds_read2_b64 they lose the 16-bit offset field that
     // holds the slot array's base, and the pairing is slower at random addresses — scripts/valu_lds_rate_probe.hip)
     auto wload = [&](int r, r4_v2u& a0, r4_v2u& a1, r4_v2u& a2, r4_v2u& a3) {
-        const uint32_t off = SLOT_B + ((ba[r] & (R4_SMASK & ~1u)) << 2);
+        const uint32_t off = SLOT_B + ((entry_of(r) & (R4_SMASK & ~1u)) << 2);
         a0 = R4_LDS(const volatile r4_v2u, off);
         a1 = R4_LDS(const volatile r4_v2u, off + 8u);
         a2 = R4_LDS(const volatile r4_v2u, off + 16u);
@@ -592,11 +600,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // One workgroup alone on a CU spends 66 cycles per wavefront and key here (LDS 29 + VALU 22 if they did not overlap at
     // all: profiles/r02_sort_rank4_one_vs_two_workgroups.log): with one window in flight per wavefront the step is bound by
     // the LDS round trip (16 windows in flight per workgroup), not by a pipe.  A second window in flight per wavefront
-    // helps where the registers are there for it — up to 10 keys per thread (9216 keys 549 -> 521 us, 8192 keys 484 ->
-    // 462 us); beyond that it spills and costs more than it hides (16 keys per thread: 904 -> 917 us).  Starting every
-    // other wavefront half a round late, wave priorities and a first-generation stagger of the two workgroups of a CU
-    // were measured too: no gain.
-    if (ITEMS <= 10) {
+    // helps (9216 keys 549 -> 521 us, 8192 keys 484 -> 462 us, 16384 keys 904 -> 886 us) once the registers are there for
+    // it: with unpacked start entries it spilled at 11 and more keys per thread and cost more than it hid (16 keys per
+    // thread: 904 -> 917 us).  Three windows in flight are slower at every size.  Starting every other wavefront half a
+    // round late, wave priorities and a first-generation stagger of the two workgroups of a CU were measured too: no gain.
+#ifndef R4_PAIRMAX
+#define R4_PAIRMAX 16
+#endif
+    if (ITEMS <= R4_PAIRMAX) {
 #pragma unroll
     for (int g = 0; g + 1 < ITEMS; g += 2) {
         r4_v2u a0, a1, a2, a3, b0, b1, b2, b3;
