@@ -9,11 +9,15 @@ Bars:
   * linear modes: <= 1e-4 * max|ref| per step, <= 1e-3 over a 13-step chain (fp32 LAPACK vs rocSOLVER vs fp64 oracle);
   * cdf through our own GEMM vs the reference output: >= 99.5 % of elements within 1e-4 * range (the map is discontinuous).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -287,6 +291,38 @@ def test_sort_match_pass_sizes_bit_exact(dev, nt, ns):
     out = ops.sort_match_seg(Seg.of(cu(t, dev)), Seg.of(cu(s, dev))).cpu().numpy()
     for i in range(2):
         assert biteq(out[i], orc.sort_match(t[i], s[0]))
+
+
+@pytest.mark.parametrize("path", ["rank3", "rank2", "radix"])
+def test_sort_match_alternate_kernels_bit_exact(dev, path):
+    """the kernels behind the default one stay selectable (OPTEX_SORT_PATH, read once per process: a child process) and
+    stay exact: the integer-key owner-ranked kernel (csrc/sort_rank3.hip), the slot-ranked one (sort_rank2.hip) and the
+    plain radix kernel, on the edge distributions + a gaussian batch, against the oracle"""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r]
+from test_gpu_parity import _sort_edge_columns, biteq, cu
+from optimaltextures_amd import ops
+from optimaltextures_amd.ops import Seg
+from oracle import oracle as orc
+dev = torch.device("cuda:0")
+for nt, ns in [(5000, 3100), (16384, 12288), (9216, 9216)]:
+    rng = np.random.default_rng(nt + ns)
+    names, t = _sort_edge_columns(nt, rng)
+    keep = [i for i, k in enumerate(names) if k != "with_inf_nan"]
+    t = t[keep]
+    s = (rng.standard_normal((1, len(keep), ns)) * 2 + 1).astype(np.float32)
+    out = ops.sort_match_seg(Seg.of(cu(t[None], dev)), Seg.of(cu(s, dev))).cpu().numpy()[0]
+    want = orc.sort_match(t, s[0])
+    for c, i in enumerate(keep):
+        assert biteq(out[c], want[c]), (nt, names[i])
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, OPTEX_SORT_PATH=path)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def _ulp_clusters(n, rng):
