@@ -56,8 +56,9 @@ class StyleSync:
     MAX_TENSORS, MAX_INTS = 160, 320
     HEADER = 3 + MAX_TENSORS * (1 + MAX_DIMS) + MAX_INTS
 
-    def __init__(self, device, src: int = 0, group=None):
-        self.device, self.src, self.group = torch.device(device), src, group
+    def __init__(self, device, src: int = 0, group=None, always: bool = False):
+        """always=True: issue the two broadcasts even in a world of one (tests: the RCCL call sequence on one GPU)"""
+        self.device, self.src, self.group, self.always = torch.device(device), src, group, always
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_moved = 0    # payload + header bytes this rank sent or received
@@ -69,7 +70,7 @@ class StyleSync:
 
     def broadcast_packed(self, tensors: Optional[List[torch.Tensor]], ints: Optional[List[int]] = None):
         """source: (list of fp32 tensors, list of ints) -> everyone: (list of tensors, list of ints)"""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return list(tensors), list(ints or [])
         header = torch.zeros(self.HEADER, dtype=torch.int64)
         flat = None

@@ -1,0 +1,63 @@
+"""The RCCL call sequence of the multi-GPU path on ONE GPU (pytest -m gpu): a one-rank "nccl" process group in a child
+process runs what bench.py --gpus N runs per rank — the packed style broadcast (int64 header + asynchronous fp32
+payload on the communicator's stream), the barrier, the max-over-ranks and per-rank gathers of the timing — and a whole
+OptimalTexture.forward with the broadcast hook against one without.  The world-size-2 semantics are covered on CPU over
+gloo (tests/test_dist.py); 8-GPU runs are the driver's."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from optimaltextures_amd import dist as otdist
+from optimaltextures_amd.driver import OptimalTexture
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+sync = otdist.StyleSync(dev, always=True)
+g = torch.Generator(device=dev).manual_seed(1)
+payload = [torch.rand(1, 11, 40, device=dev, generator=g), torch.rand(32, 11, device=dev, generator=g), torch.empty(0, 0, device=dev)]
+got, ints = sync.broadcast_packed(payload, [8, 12, 5])
+assert ints == [8, 12, 5] and len(got) == 3
+for a, b in zip(got, payload):
+    assert a.shape == b.shape and bool((a == b).all())
+assert sync.messages == 2 and sync.bytes_moved > 0
+otdist.barrier()
+assert otdist.all_reduce_max(3.5, dev) == 3.5
+assert otdist.all_gather_floats(1.25, dev) == [1.25]
+# a forward call with the hook (style side prefetched and broadcast once) equals one without, bit for bit
+def run(hook):
+    torch.manual_seed(3)
+    import numpy as np
+    np.random.seed(3)
+    tex = OptimalTexture(size=128, iters=20, passes=2, hist_mode="cdf", no_pca=False, layers=(2, 1), models_dir=None,
+                         allow_synthetic=True).to(dev)
+    if hook:
+        tex.style_sync = otdist.StyleSync(dev, always=True)
+    style = torch.rand(1, 3, 96, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+    past = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(6)).to(dev)
+    return tex.forward(past, [style], None)
+a, b = run(False), run(True)
+assert bool((a == b).all()), float((a - b).abs().max())
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_rccl_call_sequence_one_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
