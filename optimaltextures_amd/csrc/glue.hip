@@ -175,21 +175,25 @@ __global__ __launch_bounds__(256) void glue_transpose_kernel(GlueLArgs a) {
     }
 }
 
-// mixed layouts, C % 4 == 0: 64 pixels x 32 channels per block; the channels-last side moves 16 bytes per lane (128-byte
-// spans per pixel), the planar side 256-byte spans per channel row
-template <bool IN_NHWC, bool POOL>
+// mixed layouts, C % 4 == 0: TP (64 or 128) pixels x 32 channels per block; the channels-last side moves 16 bytes per
+// lane (128-byte spans per pixel), the planar side TP * 4-byte spans per channel row.  TP = 128 for rows of 128 pixels
+// and more: twice the bytes in flight per thread (the 64-pixel tile ran latency-bound: 3.5 TB/s on the 4.3 GB
+// relu1 tensor against 5.6 TB/s of the same-layout kernel).
+template <bool IN_NHWC, bool POOL, int TP>
 __global__ __launch_bounds__(256) void glue_transpose_wide_kernel(GlueLArgs a) {
-    constexpr int TP = 64, TC = 32;
+    constexpr int TC = 32;
     __shared__ float tile[TC][TP + 1];
     const int ctiles = (a.C + TC - 1) / TC;
     const int ox0 = (blockIdx.x / ctiles) * TP, c0 = (blockIdx.x % ctiles) * TC;
     const int oy = blockIdx.y, n = blockIdx.z;
     const int tid = threadIdx.x;
-    const int g = tid & 7, pp = tid >> 3;     // channels-last side: 8 lanes x float4 = 32 channels of pixel pp (+32)
-    const int px = tid & 63, cq = tid >> 6;   // planar side: 64 pixels of channel cq (+4, +8, ...)
+    const int g = tid & 7, pp = tid >> 3;                // channels-last side: 8 lanes x float4 = 32 channels of pixel pp (+32, ...)
+    const int px = tid & (TP - 1), cq = tid / TP;        // planar side: TP pixels of channel cq (+ 256 / TP, ...)
+    constexpr int ROWS = 256 / TP;                       // channel rows a pass on the planar side (4-byte accesses)
+    constexpr int ROWS2 = 512 / TP;                      // ... with 8-byte accesses
     if (IN_NHWC) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < TP / 32; k++) {
             const int p = pp + 32 * k, ox = ox0 + p, c = c0 + 4 * g;
             if (ox < a.Wo && c < a.C) {
                 const float4 v = glue_value4_nhwc<POOL>(a, n, c, oy, ox);
@@ -198,37 +202,46 @@ __global__ __launch_bounds__(256) void glue_transpose_wide_kernel(GlueLArgs a) {
         }
         __syncthreads();
         if (a.Wo % 2 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 7u) == 0) {
-            // even rows: 8-byte stores (the planar side is store-issue-bound), 32 lanes x 2 pixels, 8 channel rows a pass
-            const int p2 = (tid & 31) * 2, cr = tid >> 5;
+            // even rows: 8-byte stores (the planar side is store-issue-bound), TP / 2 lanes x 2 pixels per channel row
+            const int p2 = (tid & (TP / 2 - 1)) * 2, cr = tid / (TP / 2);
 #pragma unroll
-            for (int k = 0; k < TC / 8; k++) {
-                const int ch = cr + 8 * k, ox = ox0 + p2, c = c0 + ch;
+            for (int k = 0; k < TC / ROWS2; k++) {
+                const int ch = cr + ROWS2 * k, ox = ox0 + p2, c = c0 + ch;
                 if (ox < a.Wo && c < a.C)   // Wo and ox even: ox + 1 < Wo as well
                     *reinterpret_cast<float2*>(a.out + (((size_t)n * a.C + c) * a.Ho + oy) * a.Wo + ox) =
                         make_float2(tile[ch][p2], tile[ch][p2 + 1]);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < TC / 4; k++) {
-                const int ch = cq + 4 * k, ox = ox0 + px, c = c0 + ch;
+            for (int k = 0; k < TC / ROWS; k++) {
+                const int ch = cq + ROWS * k, ox = ox0 + px, c = c0 + ch;
                 if (ox < a.Wo && c < a.C) a.out[(((size_t)n * a.C + c) * a.Ho + oy) * a.Wo + ox] = tile[ch][px];
             }
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < TC / 4; k++) {
-            const int ch = cq + 4 * k, ox = ox0 + px, c = c0 + ch;
+        for (int k = 0; k < TC / ROWS; k++) {
+            const int ch = cq + ROWS * k, ox = ox0 + px, c = c0 + ch;
             if (ox < a.Wo && c < a.C) tile[ch][px] = glue_value<false, POOL>(a, n, c, oy, ox, a.bias ? a.bias[c] : 0.f);
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < TP / 32; k++) {
             const int p = pp + 32 * k, ox = ox0 + p, c = c0 + 4 * g;
             if (ox < a.Wo && c < a.C)
                 *reinterpret_cast<float4*>(a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.C + c) =
                     make_float4(tile[4 * g + 0][p], tile[4 * g + 1][p], tile[4 * g + 2][p], tile[4 * g + 3][p]);
         }
     }
+}
+
+// OPTEX_GLUE_TP128=0: 64-pixel tiles for every row length (measurements)
+static int glue_tp128_enabled() {
+    static const int v = [] {
+        const char* e = getenv("OPTEX_GLUE_TP128");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return v;
 }
 
 }  // namespace optex
@@ -313,13 +326,23 @@ extern "C" int optex_vgg_glue_layout(const float* x, const float* bias, float* o
         else hipLaunchKernelGGL(glue_nhwc_kernel<false>, grid, dim3(256), 0, st, a);
     } else if (in_nhwc != out_nhwc && C % 4 == 0 && (reinterpret_cast<uintptr_t>(in_nhwc ? x : out) % 16 == 0) &&
                (!bias || !in_nhwc || reinterpret_cast<uintptr_t>(bias) % 16 == 0)) {
-        dim3 grid((unsigned)(((a.Wo + 63) / 64) * ((C + 31) / 32)), (unsigned)a.Ho, (unsigned)N);
-        if (in_nhwc) {
-            if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<true, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((glue_transpose_wide_kernel<true, false>), grid, dim3(256), 0, st, a);
+        const bool wide = a.Wo >= 128 && glue_tp128_enabled();
+        const int tp = wide ? 128 : 64;
+        dim3 grid((unsigned)(((a.Wo + tp - 1) / tp) * ((C + 31) / 32)), (unsigned)a.Ho, (unsigned)N);
+        if (wide) {
+            if (in_nhwc) {
+                if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<true, true, 128>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((glue_transpose_wide_kernel<true, false, 128>), grid, dim3(256), 0, st, a);
+            } else {
+                if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<false, true, 128>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((glue_transpose_wide_kernel<false, false, 128>), grid, dim3(256), 0, st, a);
+            }
+        } else if (in_nhwc) {
+            if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<true, true, 64>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((glue_transpose_wide_kernel<true, false, 64>), grid, dim3(256), 0, st, a);
         } else {
-            if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<false, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((glue_transpose_wide_kernel<false, false>), grid, dim3(256), 0, st, a);
+            if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<false, true, 64>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((glue_transpose_wide_kernel<false, false, 64>), grid, dim3(256), 0, st, a);
         }
     } else if (in_nhwc != out_nhwc) {
         dim3 grid((unsigned)(((a.Wo + 31) / 32) * ((C + 31) / 32)), (unsigned)a.Ho, (unsigned)N);
