@@ -179,22 +179,23 @@ __global__ __launch_bounds__(256) void glue_transpose_kernel(GlueLArgs a) {
 // lane (128-byte spans per pixel), the planar side TP * 4-byte spans per channel row.  TP = 128 for rows of 128 pixels
 // and more: twice the bytes in flight per thread (the 64-pixel tile ran latency-bound: 3.5 TB/s on the 4.3 GB
 // relu1 tensor against 5.6 TB/s of the same-layout kernel).
-template <bool IN_NHWC, bool POOL, int TP>
+template <bool IN_NHWC, bool POOL, int TP, int TC = 32>
 __global__ __launch_bounds__(256) void glue_transpose_wide_kernel(GlueLArgs a) {
-    constexpr int TC = 32;
+    constexpr int GL = TC / 4;                           // lanes per pixel on the channels-last side
     __shared__ float tile[TC][TP + 1];
     const int ctiles = (a.C + TC - 1) / TC;
     const int ox0 = (blockIdx.x / ctiles) * TP, c0 = (blockIdx.x % ctiles) * TC;
     const int oy = blockIdx.y, n = blockIdx.z;
     const int tid = threadIdx.x;
-    const int g = tid & 7, pp = tid >> 3;                // channels-last side: 8 lanes x float4 = 32 channels of pixel pp (+32, ...)
+    const int g = tid & (GL - 1), pp = tid / GL;         // channels-last side: GL lanes x float4 = TC channels of pixel pp (+256 / GL, ...)
+    constexpr int PPS = 256 / GL;                        // pixels a pass on the channels-last side
     const int px = tid & (TP - 1), cq = tid / TP;        // planar side: TP pixels of channel cq (+ 256 / TP, ...)
     constexpr int ROWS = 256 / TP;                       // channel rows a pass on the planar side (4-byte accesses)
     constexpr int ROWS2 = 512 / TP;                      // ... with 8-byte accesses
     if (IN_NHWC) {
 #pragma unroll
-        for (int k = 0; k < TP / 32; k++) {
-            const int p = pp + 32 * k, ox = ox0 + p, c = c0 + 4 * g;
+        for (int k = 0; k < TP / PPS; k++) {
+            const int p = pp + PPS * k, ox = ox0 + p, c = c0 + 4 * g;
             if (ox < a.Wo && c < a.C) {
                 const float4 v = glue_value4_nhwc<POOL>(a, n, c, oy, ox);
                 tile[4 * g + 0][p] = v.x; tile[4 * g + 1][p] = v.y; tile[4 * g + 2][p] = v.z; tile[4 * g + 3][p] = v.w;
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(256) void glue_transpose_wide_kernel(GlueLArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TP / 32; k++) {
-            const int p = pp + 32 * k, ox = ox0 + p, c = c0 + 4 * g;
+        for (int k = 0; k < TP / PPS; k++) {
+            const int p = pp + PPS * k, ox = ox0 + p, c = c0 + 4 * g;
             if (ox < a.Wo && c < a.C)
                 *reinterpret_cast<float4*>(a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.C + c) =
                     make_float4(tile[4 * g + 0][p], tile[4 * g + 1][p], tile[4 * g + 2][p], tile[4 * g + 3][p]);
@@ -328,8 +329,14 @@ extern "C" int optex_vgg_glue_layout(const float* x, const float* bias, float* o
                (!bias || !in_nhwc || reinterpret_cast<uintptr_t>(bias) % 16 == 0)) {
         const bool wide = a.Wo >= 128 && glue_tp128_enabled();
         const int tp = wide ? 128 : 64;
-        dim3 grid((unsigned)(((a.Wo + tp - 1) / tp) * ((C + 31) / 32)), (unsigned)a.Ho, (unsigned)N);
-        if (wide) {
+        // channels-last -> planar with C % 64 == 0: 64 channels per tile, 256-byte spans per pixel on the read side (4.03 ->
+        // 4.25 TB/s; the other direction loses with it: 3.6 -> 2.3 TB/s)
+        const bool deep = wide && in_nhwc && C % 64 == 0;
+        dim3 grid((unsigned)(((a.Wo + tp - 1) / tp) * ((C + (deep ? 63 : 31)) / (deep ? 64 : 32))), (unsigned)a.Ho, (unsigned)N);
+        if (deep) {
+            if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<true, true, 128, 64>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((glue_transpose_wide_kernel<true, false, 128, 64>), grid, dim3(256), 0, st, a);
+        } else if (wide) {
             if (in_nhwc) {
                 if (pool) hipLaunchKernelGGL((glue_transpose_wide_kernel<true, true, 128>), grid, dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((glue_transpose_wide_kernel<true, false, 128>), grid, dim3(256), 0, st, a);
