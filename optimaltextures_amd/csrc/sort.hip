@@ -562,6 +562,8 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
                 if ((rc = launch_rank_match3(ITEMS, a, ncols, st))) return rc;  // owner-ranked, integer keys (sort_rank3.hip)
             } else if (MODE == SORT_MATCH && sort_path_override() != 2) {
                 if ((rc = launch_rank_match4(ITEMS, a, ncols, st))) return rc;  // owner-ranked, float domain (sort_rank4.hip)
+            } else if (MODE == SORT_EMIT && sort_path_override() == 0) {
+                if ((rc = launch_rank_emit4(ITEMS, a, ncols, st))) return rc;   // the same kernel, keys / indices by rank
             } else {
                 hipLaunchKernelGGL(rkern, dim3(ncols), dim3(SORT_NT), rank_lds_bytes<ITEMS>(MODE == SORT_MATCH), st, a);
             }

@@ -108,5 +108,7 @@ int launch_rank_match(int items, const SortArgs& a, int ncols, hipStream_t st);
 int launch_rank_match3(int items, const SortArgs& a, int ncols, hipStream_t st);
 // owner-ranked match kernel in the float domain, built on 2-cycle VALU instructions (sort_rank4.hip), the default
 int launch_rank_match4(int items, const SortArgs& a, int ncols, hipStream_t st);
+// the same kernel emitting sorted keys / pixel indices (optex_sort_columns)
+int launch_rank_emit4(int items, const SortArgs& a, int ncols, hipStream_t st);
 
 }  // namespace optex

@@ -151,7 +151,9 @@ __device__ __forceinline__ void r4_count4(uint32_t& lt, uint32_t& le, const uint
 
 // NT threads per workgroup (1024, or 512 / 256 for short columns: more columns resident per CU).  FULL: the column
 // fills all ITEMS * NT registers (no validity tests at all).
-template <int ITEMS, bool VEC, int NT, bool FULL>
+// MODE = SORT_MATCH: out[pixel] = sorted_source[q(rank)].  MODE = SORT_EMIT (optex_sort_columns): the sorted keys and / or
+// their pixel indices, contiguous [column, n], written by rank through the (then dead) slot array.
+template <int ITEMS, bool VEC, int NT, bool FULL, int MODE = SORT_MATCH>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match4_kernel(SortArgs a) {
     using K = R4<ITEMS, NT>;
     constexpr int NW = NT / 64;
@@ -180,9 +182,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int xseg = (a.x_n_seg == 1) ? 0 : seg;
     const float* src = a.keys + (size_t)xseg * a.ss + (size_t)c * a.ld;
     const int sseg = (a.src_n_seg == 1) ? 0 : seg;
-    const float* ssrt = a.src_sorted + ((size_t)sseg * a.C + c) * a.ns;
-    float* o = a.out + (size_t)seg * a.oss + (size_t)c * a.ldo;
-    const unsigned ns = (unsigned)a.ns;
+    const float* ssrt = MODE == SORT_MATCH ? a.src_sorted + ((size_t)sseg * a.C + c) * a.ns : nullptr;
+    float* o = MODE == SORT_MATCH ? a.out + (size_t)seg * a.oss + (size_t)c * a.ldo : nullptr;
+    const unsigned ns = MODE == SORT_MATCH ? (unsigned)a.ns : 1u;
     const int n = FULL ? CAP : (int)a.n;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // VEC: the first 4 * Q registers are Q 16-byte loads (4 neighbouring pixels in one thread), the remaining T = ITEMS % 4
@@ -296,7 +298,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             return;
         }
         // constant column: already sorted, rank = pixel index
-        for (int e = tid; e < n; e += NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+        if (MODE == SORT_MATCH) {
+            for (int e = tid; e < n; e += NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+        } else {
+            for (int e = tid; e < n; e += NT) {
+                if (a.out_keys) a.out_keys[(size_t)col * n + e] = lo;
+                if (a.out_idx) a.out_idx[(size_t)col * n + e] = (uint32_t)e;
+            }
+        }
         return;
     }
     const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     asm volatile("" : "+v"(tid9));
     r4_v4f sv[Q > 0 ? Q : 1];
     float svt[T > 0 ? T : 1];
-    if (VEC && stage && svec) {
+    if (MODE == SORT_MATCH && VEC && stage && svec) {
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const unsigned e0 = (unsigned)(q * NT + tid9) * 4u;
@@ -710,6 +719,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     __syncthreads();
     SORT_PROBE(8);
+    if (MODE == SORT_EMIT) {
+        // ---- 9E. sorted keys / pixel indices: every owner writes its key (then its pixel number) to slot[rank] — every
+        //          slot has been read — and the column leaves the LDS in order with 16-byte stores
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            if ((ba[r] & R4_TAG) != 0u) ba[r] = qres[ba[r] & ~R4_TAG];  // rare: most wavefront rows branch over it
+        }
+        const size_t obase = (size_t)col * (size_t)n;
+        const bool ovec = (n % 4 == 0) && a.out_vec;
+        auto drain = [&](uint32_t* dst) {
+            __syncthreads();
+            if (ovec) {
+                for (int e = tid9 * 4; e < n; e += NT * 4)
+                    *reinterpret_cast<uint4*>(dst + obase + e) = *reinterpret_cast<const uint4*>(slot + e);
+            } else {
+                for (int e = tid9; e < n; e += NT) dst[obase + e] = slot[e];
+            }
+        };
+        if (a.out_keys) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if (valid(r)) R4_LDS(float, SLOT_B + (ba[r] << 2)) = x[r];
+            drain(reinterpret_cast<uint32_t*>(a.out_keys));
+        }
+        if (a.out_idx) {
+            if (a.out_keys) __syncthreads();  // the keys have left the slot array
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if (valid(r)) R4_LDS(uint32_t, SLOT_B + (ba[r] << 2)) = (uint32_t)elem(r);
+            drain(a.out_idx);
+        }
+        SORT_PROBE(10);
+        return;
+    }
     // ---- 9. out[pixel] = sorted_source[q(rank)]: the source column is staged in the slot array (every slot has been
     //         read), each owner picks its values and leaves with 16-byte stores
     float* val = reinterpret_cast<float*>(slot);
@@ -793,28 +836,32 @@ static int launch_one4(KernT kern, DeviceOnce& once, size_t lds, const SortArgs&
     return OPTEX_OK;
 }
 
-template <int ITEMS, int NT>
-static int launch_rank_match4_items(SortArgs a, int ncols, hipStream_t st) {
+template <int ITEMS, int NT, int MODE>
+static int launch_rank4_items(SortArgs a, int ncols, hipStream_t st) {
     // 16-byte loads for the first 4 * (ITEMS / 4) registers; without scalar rows behind them the column must end on a quad
     constexpr bool CANVEC = ITEMS >= 4;
     const bool in_vec = CANVEC && (ITEMS % 4 != 0 || a.n % 4 == 0) && a.ld % 4 == 0 && a.ss % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
-    a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
+    if (MODE == SORT_MATCH)
+        a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
+    else  // contiguous [column, n] outputs: 16-byte stores when the columns start on 16-byte boundaries
+        a.out_vec = (a.n % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out_keys) & 15u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.out_idx) & 15u) == 0) ? 1 : 0;
     const size_t lds = R4<ITEMS, NT>::LDS;
     const bool full = a.n == (long)ITEMS * NT;
     int rc;
     if (in_vec && full) {
         static DeviceOnce once;
-        rc = launch_one4(rank_match4_kernel<ITEMS, CANVEC, NT, true>, once, lds, a, ncols, NT, st);
+        rc = launch_one4(rank_match4_kernel<ITEMS, CANVEC, NT, true, MODE>, once, lds, a, ncols, NT, st);
     } else if (in_vec) {
         static DeviceOnce once;
-        rc = launch_one4(rank_match4_kernel<ITEMS, CANVEC, NT, false>, once, lds, a, ncols, NT, st);
+        rc = launch_one4(rank_match4_kernel<ITEMS, CANVEC, NT, false, MODE>, once, lds, a, ncols, NT, st);
     } else if (full) {
         static DeviceOnce once;
-        rc = launch_one4(rank_match4_kernel<ITEMS, false, NT, true>, once, lds, a, ncols, NT, st);
+        rc = launch_one4(rank_match4_kernel<ITEMS, false, NT, true, MODE>, once, lds, a, ncols, NT, st);
     } else {
         static DeviceOnce once;
-        rc = launch_one4(rank_match4_kernel<ITEMS, false, NT, false>, once, lds, a, ncols, NT, st);
+        rc = launch_one4(rank_match4_kernel<ITEMS, false, NT, false, MODE>, once, lds, a, ncols, NT, st);
     }
     if (rc) return rc;
     return check_launch("rank_match4_kernel");
@@ -841,8 +888,8 @@ static int extra_nt_enabled() {
     return v;
 }
 
-int launch_rank_match4(int items, const SortArgs& a0, int ncols, hipStream_t st) {
-    (void)items;
+template <int MODE>
+static int launch_rank4(const SortArgs& a0, int ncols, hipStream_t st) {
     SortArgs a = a0;
     const long n = a.n;
     // two 1024-thread workgroups per CU for columns above 8192 keys; the smaller workgroups of shorter columns come four
@@ -854,37 +901,48 @@ int launch_rank_match4(int items, const SortArgs& a0, int ncols, hipStream_t st)
     // 227 us on 512 x 8 against 287 us on 256 x 16 and 323 us on 1024 x 4; 8192 keys 486 us on 1024 x 8 against 580 us on
     // 512 x 16; 5120 keys 287 us on 512 x 10 against 381 us on 1024 x 5.  Above 10240 keys a workgroup cannot have more
     // threads, and the keys per thread grow to 16.
-    if (n <= 2048) return launch_rank_match4_items<2, SORT_NT>(a, ncols, st);
+    if (n <= 2048) return launch_rank4_items<2, SORT_NT, MODE>(a, ncols, st);
     if (n <= 2560) {
-        if (n <= 9 * 256) return launch_rank_match4_items<9, 256>(a, ncols, st);
-        return launch_rank_match4_items<10, 256>(a, ncols, st);
+        if (n <= 9 * 256) return launch_rank4_items<9, 256, MODE>(a, ncols, st);
+        return launch_rank4_items<10, 256, MODE>(a, ncols, st);
     }
     if (n <= 5120) {
         switch ((int)((n + 511) / 512)) {
-            case 6: return launch_rank_match4_items<6, 512>(a, ncols, st);
-            case 7: return launch_rank_match4_items<7, 512>(a, ncols, st);
-            case 8: return launch_rank_match4_items<8, 512>(a, ncols, st);
-            case 9: return launch_rank_match4_items<9, 512>(a, ncols, st);
-            default: return launch_rank_match4_items<10, 512>(a, ncols, st);
+            case 6: return launch_rank4_items<6, 512, MODE>(a, ncols, st);
+            case 7: return launch_rank4_items<7, 512, MODE>(a, ncols, st);
+            case 8: return launch_rank4_items<8, 512, MODE>(a, ncols, st);
+            case 9: return launch_rank4_items<9, 512, MODE>(a, ncols, st);
+            default: return launch_rank4_items<10, 512, MODE>(a, ncols, st);
         }
     }
     // 6400 keys (a pass size of the 512^2 schedule) fill 640 threads x 10 keys exactly, three workgroups to a CU.  (Tried
     // and slower: 9216 keys on 576 x 16, three workgroups of nine wavefronts to a CU, 822 us against 573 us on 1024 x 9;
     // 12544 keys on 896 x 14, 936 us against 826 us on 1024 x 13.)
-    if (n == 10 * 640 && extra_nt_enabled()) return launch_rank_match4_items<10, 640>(a, ncols, st);
+    if (n == 10 * 640 && extra_nt_enabled()) return launch_rank4_items<10, 640, MODE>(a, ncols, st);
     switch ((int)((n + 1023) / 1024)) {
-        case 6: return launch_rank_match4_items<6, 1024>(a, ncols, st);
-        case 7: return launch_rank_match4_items<7, 1024>(a, ncols, st);
-        case 8: return launch_rank_match4_items<8, 1024>(a, ncols, st);
-        case 9: return launch_rank_match4_items<9, 1024>(a, ncols, st);
-        case 10: return launch_rank_match4_items<10, 1024>(a, ncols, st);
-        case 11: return launch_rank_match4_items<11, 1024>(a, ncols, st);
-        case 12: return launch_rank_match4_items<12, 1024>(a, ncols, st);
-        case 13: return launch_rank_match4_items<13, 1024>(a, ncols, st);
-        case 14: return launch_rank_match4_items<14, 1024>(a, ncols, st);
-        case 15: return launch_rank_match4_items<15, 1024>(a, ncols, st);
-        default: return launch_rank_match4_items<16, 1024>(a, ncols, st);
+        case 6: return launch_rank4_items<6, 1024, MODE>(a, ncols, st);
+        case 7: return launch_rank4_items<7, 1024, MODE>(a, ncols, st);
+        case 8: return launch_rank4_items<8, 1024, MODE>(a, ncols, st);
+        case 9: return launch_rank4_items<9, 1024, MODE>(a, ncols, st);
+        case 10: return launch_rank4_items<10, 1024, MODE>(a, ncols, st);
+        case 11: return launch_rank4_items<11, 1024, MODE>(a, ncols, st);
+        case 12: return launch_rank4_items<12, 1024, MODE>(a, ncols, st);
+        case 13: return launch_rank4_items<13, 1024, MODE>(a, ncols, st);
+        case 14: return launch_rank4_items<14, 1024, MODE>(a, ncols, st);
+        case 15: return launch_rank4_items<15, 1024, MODE>(a, ncols, st);
+        default: return launch_rank4_items<16, 1024, MODE>(a, ncols, st);
     }
+}
+
+int launch_rank_match4(int items, const SortArgs& a, int ncols, hipStream_t st) {
+    (void)items;
+    return launch_rank4<SORT_MATCH>(a, ncols, st);
+}
+
+// optex_sort_columns on the same kernel (keys and / or indices by rank): called by launch_sort_items<ITEMS, SORT_EMIT>
+int launch_rank_emit4(int items, const SortArgs& a, int ncols, hipStream_t st) {
+    (void)items;
+    return launch_rank4<SORT_EMIT>(a, ncols, st);
 }
 
 }  // namespace optex
