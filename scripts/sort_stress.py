@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised stress of optex_sort_match against the oracle (not part of the test suite: minutes of CPU oracle time).
+"""Randomised stress of optex_sort_match and optex_sort_columns against the oracle (not part of the test suite: minutes of CPU oracle time).
 Column lengths around every workgroup-shape boundary of csrc/sort_rank4.hip, source lengths below / equal / above, mixed
 edge distributions per column, unaligned views.   python scripts/sort_stress.py [n_cases] [seed]"""
 import os
@@ -62,6 +62,15 @@ def main():
             if not np.array_equal(out[k], want):
                 bad += 1
                 print(f"MISMATCH case {it}: n={n} ns={ns} S={S} C={C} off={off} segment {k}", flush=True)
+        # optex_sort_columns (keys + stable indices) on the same columns
+        tc = np.ascontiguousarray(t[:, :, off:])
+        keys, idx = ops.sort_columns(torch.from_numpy(tc).to(dev))
+        keys, idx = keys.cpu().numpy(), idx.cpu().numpy().view(np.uint32)
+        for k in range(S):
+            ok, oi = orc.sort_columns(tc[k])
+            if not (np.array_equal(idx[k], oi) and np.array_equal(keys[k].view(np.uint32), ok.view(np.uint32))):
+                bad += 1
+                print(f"MISMATCH (sort_columns) case {it}: n={n} S={S} C={C} segment {k}", flush=True)
     print(f"{cases} cases, {bad} mismatches")
     return 1 if bad else 0
 
