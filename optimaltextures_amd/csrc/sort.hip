@@ -386,8 +386,17 @@ __global__ __launch_bounds__(SORT_NT) void sort_columns_kernel(SortArgs a) {
     uint32_t* cnt = sidx + CAP;
     uint32_t* wtot = cnt + SORT_CSTR * SORT_NW;  // [16] scan scratch
 
-    const int col = blockIdx.x, seg = col / a.C, c = col % a.C;
-    if (a.only_flagged && a.flags[col] == 0) return;
+    // As the sweep behind a rank kernel (only_flagged) the launch has one workgroup per CU, each walking the columns with
+    // a stride and taking the flagged ones: 16384 workgroups of 1024 threads and 128 KiB of LDS that start only to find
+    // their flag clear cost 30 us per launch (5 % of the match they follow).
+    // (64 flags per round, one per lane, then the set bits: a serial walk is 64 dependent loads per workgroup, ~25 us)
+    for (int base = blockIdx.x; base < a.ncols; base += (int)gridDim.x * 64) {
+    const long mycol = (long)base + (long)(threadIdx.x & 63) * (long)gridDim.x;
+    unsigned long long todo = __ballot(mycol < a.ncols && (!a.only_flagged || a.flags[mycol] != 0));
+    while (todo) {
+    const int col = base + __builtin_ctzll(todo) * (int)gridDim.x;
+    todo &= todo - 1ull;
+    const int seg = col / a.C, c = col % a.C;
     const int xseg = (a.x_n_seg == 1) ? 0 : seg;
     const float* src = a.keys + (size_t)xseg * a.ss + (size_t)c * a.ld;
     const int n = (int)a.n;
@@ -505,7 +514,13 @@ __global__ __launch_bounds__(SORT_NT) void sort_columns_kernel(SortArgs a) {
         float* o = a.out + (size_t)seg * a.oss + (size_t)c * a.ldo;
         for (int i = tid; i < n; i += SORT_NT) o[i] = sval[i];
     }
+    __syncthreads();  // the LDS arrays are reused by the next column of this workgroup
+    }
+    }
 }
+
+
+int device_cu_count();
 
 // ================================================================================================ host side
 // OPTEX_SORT_PATH=radix forces the general kernel, =rank1 the one-column-per-CU ranking kernel for the match as well,
@@ -578,7 +593,9 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
     // when it only sweeps up flagged columns the radix launch is accounted with zero algorithmic bytes
     ProfScope prof(use_rank ? KC_SORT_FALLBACK : (MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH), st, 0.0,
                    use_rank ? 0.0 : per_elem * (double)a.n * ncols);
-    hipLaunchKernelGGL(kern, dim3(ncols), dim3(SORT_NT), lds, st, a);
+    int grid = ncols;
+    if (use_rank && device_cu_count() < grid) grid = device_cu_count();  // sweep: one workgroup per CU walks the flags
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SORT_NT), lds, st, a);
     return check_launch("sort_columns_kernel");
 }
 
