@@ -13,8 +13,6 @@
 //
 // Roofline: 2*M*K*n flop against 4*(K + M)*n + 4*K*M bytes; at C = 256 the intensity is 64 flop/B, i.e.
 // MFMA-bound (157 TFLOP/s fp32 matrix peak); below C ~ 80 it turns HBM-bound.
-#include <cstdlib>
-
 #include "gemm_args.h"
 
 namespace optex {
@@ -278,8 +276,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
 // ---- Hot-loop specialisation (channel-major in / out, no epilogue extras, full pixel tiles): the same block structure
 // on v_mfma_f32_16x16x4_f32 — 4 accumulator registers per MFMA instead of 16, i.e. half the accumulator read / write
 // traffic per flop.  Bit-identical results (both MFMA shapes are k-ordered fma chains); measured 118.6 vs 116.0 TFLOP/s
-// at M = K = 256, n = 32 x 16384 (the kernel is power-limited: less register-file traffic buys clock).
-// OPTEX_GEMM_MFMA16=0 disables it.
+// at M = K = 256, n = 32 x 16384.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // EXTRA = true adds the operand centring (bsub), the output bias (badd) and the content blend of the general kernel, with
@@ -459,14 +456,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
     }
 }
 
-static int gemm_mfma16_env() {
-    static const int v = [] {
-        const char* e = getenv("OPTEX_GEMM_MFMA16");
-        return e ? atoi(e) : 1;
-    }();
-    return v;
-}
-
 template <int BM, int BN, int BK, int WGM, int WGN, bool BPM, bool OPM>
 static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
     constexpr int NT = 64 * WGM * WGN;
@@ -490,8 +479,9 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
 //   256x128 tile / 512 threads  113 TFLOP/s   <- whole M in one block: the feature map is read from HBM exactly once
 //   128x128 tile / 256 threads  109 TFLOP/s      (every pixel tile is fetched by two m-tiles)
 // Software-pipelined LDS fragment reads, LDS refill under the MFMAs, BK = 8 / 32, and an LDS-free variant streaming
-// fragments straight from L1/L2 were all tried and measured 72-99 TFLOP/s: at 70 % MFMA utilisation the chip already
-// draws 1350 W of its 1400 W cap (rocm-smi), so the kernel is power-limited, not issue-limited.
+// fragments straight from L1/L2 were all tried and measured 72-99 TFLOP/s.  The kernel is issue-bound (one barrier per
+// 16-deep K chunk with two waves per SIMD: SQ_WAIT_INST_ANY 0.68), not power-limited: 1243 W mean of the 1400 W cap at
+// top clock (profiles/r02_power_gemm_rocm_smi.md).
 int device_cu_count();
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -505,7 +495,7 @@ static bool output_vec(const GemmArgs& a) {
 static bool hot_shape(const GemmArgs& a, int n_cu) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
-    return big >= 2LL * n_cu && a.M > 64 && gemm_mfma16_env() && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 && a.M > 128 &&
+    return big >= 2LL * n_cu && a.M > 64 && !a.epi && a.n % 128 == 0 && a.M % 4 == 0 && a.M > 128 &&
            huge >= 2LL * n_cu;
 }
 

@@ -236,15 +236,6 @@ __global__ __launch_bounds__(256) void glue_transpose_wide_kernel(GlueLArgs a) {
     }
 }
 
-// OPTEX_GLUE_TP128=0: 64-pixel tiles for every row length (measurements)
-static int glue_tp128_enabled() {
-    static const int v = [] {
-        const char* e = getenv("OPTEX_GLUE_TP128");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    return v;
-}
-
 }  // namespace optex
 
 using namespace optex;
@@ -327,7 +318,7 @@ extern "C" int optex_vgg_glue_layout(const float* x, const float* bias, float* o
         else hipLaunchKernelGGL(glue_nhwc_kernel<false>, grid, dim3(256), 0, st, a);
     } else if (in_nhwc != out_nhwc && C % 4 == 0 && (reinterpret_cast<uintptr_t>(in_nhwc ? x : out) % 16 == 0) &&
                (!bias || !in_nhwc || reinterpret_cast<uintptr_t>(bias) % 16 == 0)) {
-        const bool wide = a.Wo >= 128 && glue_tp128_enabled();
+        const bool wide = a.Wo >= 128;
         const int tp = wide ? 128 : 64;
         // channels-last -> planar with C % 64 == 0: 64 channels per tile, 256-byte spans per pixel on the read side (4.03 ->
         // 4.25 TB/s; the other direction loses with it: 3.6 -> 2.3 TB/s)

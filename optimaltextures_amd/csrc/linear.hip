@@ -5,7 +5,6 @@
 // instead of 2*n*C^2) and mirrored in the finalize kernel.  Centring happens while staging tiles into LDS, exactly
 // like the reference centres before the GEMM (no E[x^2] - mu^2 cancellation).  Partials of the K (= pixel) split
 // are reduced in a fixed order, so the result is deterministic.
-#include <cstdlib>
 
 #include "optex_common.h"
 
@@ -364,23 +363,20 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
         const int b64 = (C + GT - 1) / GT;
         ProfScope prof(KC_GRAM, st, 2.0 * (b64 * (b64 + 1) / 2) * GT * GT * (double)n * n_seg, 4.0 * (double)n * C * n_seg);
         if (big) {
-            static const int gk = [] {
-                const char* e = getenv("OPTEX_GRAM_GK");
-                return (e && atoi(e) == 16) ? 16 : 32;
-            }();
+            constexpr int gk = 32;
             const size_t lds = (size_t)4 * GT2 * (gk + 1) * sizeof(float);
-            auto kern = gk == 32 ? gram128_kernel<32> : gram128_kernel<16>;
-            static bool attr_done[64][2] = {};
+            auto kern = gram128_kernel<gk>;
+            static bool attr_done[64] = {};
             int dev = 0;
             (void)hipGetDevice(&dev);
-            if (!attr_done[dev & 63][gk == 32]) {
+            if (!attr_done[dev & 63]) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds);
                 if (e != hipSuccess) {
                     set_error("gram128_kernel: cannot reserve LDS: %s", hipGetErrorString(e));
                     return OPTEX_E_LAUNCH;
                 }
-                attr_done[dev & 63][gk == 32] = true;
+                attr_done[dev & 63] = true;
             }
             hipLaunchKernelGGL(kern, dim3(pairs, splits, n_seg), dim3(256), lds, st, x, ld, seg_stride, n, C, mu, chunk, tiles,
                                part, vec);

@@ -38,11 +38,7 @@ struct SortArgs {
     int only_flagged;                                         // radix kernel: skip columns whose flag is 0
     double inv_2nt;                                           // 1 / (2 * n) for the quantile index
     int ncols;                                                // C * n_seg
-    int out_vec;                                              // rank_match_kernel: `out` takes 16-byte stores
-    int stagger;                                              // rank_match4_kernel: workgroups of the first generation (0 = no stagger)
-#ifdef R2_DEBUG
-    uint32_t* dbg;                                            // scripts/sort_rank2_debug.hip
-#endif
+    int out_vec;                                              // rank_match4_kernel: `out` takes 16-byte stores
 #ifdef OPTEX_SORT_PROBE
     long long* probe;                                         // [ncols, 16] phase timestamps (scripts/sort_phase_probe.hip)
 #endif
@@ -102,13 +98,8 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d) {
 size_t sort_large_ws_bytes(long n, int ncols);
 int sort_large(int mode, const SortArgs& a, int ncols, void* ws, hipStream_t st);
 
-// two-columns-per-CU match kernel (sort_rank2.hip); items = 2 / 4 / 8 / 12 / 16 keys per thread
-int launch_rank_match(int items, const SortArgs& a, int ncols, hipStream_t st);
-// owner-ranked two-columns-per-CU match kernel on integer totalOrder keys (sort_rank3.hip)
-int launch_rank_match3(int items, const SortArgs& a, int ncols, hipStream_t st);
-// owner-ranked match kernel in the float domain, built on 2-cycle VALU instructions (sort_rank4.hip), the default
-int launch_rank_match4(int items, const SortArgs& a, int ncols, hipStream_t st);
-// the same kernel emitting sorted keys / pixel indices (optex_sort_columns)
-int launch_rank_emit4(int items, const SortArgs& a, int ncols, hipStream_t st);
+// owner-ranked ranking-by-counting kernel in the float domain (sort_rank4.hip): mode = SORT_MATCH (the transport match) or
+// SORT_EMIT (sorted keys / pixel indices, optex_sort_columns)
+int launch_rank4(int mode, const SortArgs& a, int ncols, hipStream_t st);
 
 }  // namespace optex

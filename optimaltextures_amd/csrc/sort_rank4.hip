@@ -1,10 +1,10 @@
 // sort_rank4.hip — rank_match4_kernel: the exact 1-D transport match (north-star addition; specification =
-// oracle/optex_oracle.c orc_sort_match), owner-ranked like sort_rank3.hip, rebuilt around what a VALU instruction COSTS on
+// oracle/optex_oracle.c orc_sort_match), owner-ranked, built around what a VALU instruction COSTS on
 // gfx950.  Measured (scripts/valu_lds_rate_probe.hip, profiles/r02_valu_lds_rate_probe.log, 8 waves per SIMD): a
 // wave-instruction takes ~2.4 cycles of its SIMD if it is v_add_u32 / v_and_b32 / v_mov_b32 / v_mul_f32 / v_fma_f32 (and
-// v_sub / v_add_f32), and ~4.1 cycles if it is anything else the old kernel was made of — v_cmp_*, v_addc_co_u32,
+// v_sub / v_add_f32), and ~4.1 cycles if it is anything else the previous generation (an integer-key owner-ranked kernel, round 2) was made of — v_cmp_*, v_addc_co_u32,
 // v_cndmask, v_min/max, shifts, v_bfe, v_lshl_add, v_mad_u24, every v_cvt, every fp64 op.  At 141 mostly 4-cycle
-// instructions per key rank_match3_kernel kept the VALU busy ~90 % of its run (SQ_ACTIVE_INST_VALU x 4 / cycles): it was
+// instructions per key that kernel kept the VALU busy ~90 % of its run (SQ_ACTIVE_INST_VALU x 4 / cycles): it was
 // VALU-bound, not LDS-bound.  This kernel spends the fast class wherever the work allows it:
 //
 //   1. FLOAT-DOMAIN keys.  The slots hold the raw fp32 values and every comparison is a float comparison, so the
@@ -29,8 +29,8 @@
 //   5. Validity tests only on the register rows that can be ragged (the last row, or the last 16-byte quad), none when
 //      the column fills the workgroup exactly.
 //
-// Everything else — histogram-equalised monotone bucket map, returning count atomics, one-barrier scan, all-equal big
-// buckets, tie list, radix fallback through the flags, staged sorted source column, 16-byte stores — is sort_rank3.hip's.
+// Around that: histogram-equalised monotone bucket map, returning count atomics, one-barrier scan, all-equal big buckets,
+// tie list, radix fallback through the flags (sort.hip), staged sorted source column, 16-byte stores.
 #include "sort_common.h"
 #include <type_traits>
 
@@ -201,16 +201,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) {
         if (threadIdx.x == 0) a.flags[blockIdx.x] = 1;  // never on this toolchain: the radix kernel would take every column
         return;
-    }
-    // Two workgroups share a CU.  Launched together they run in lock step — both waiting for their column, then both on
-    // the LDS, then both on the VALU — and leave each unit idle while the other phase lasts.  In the first generation the
-    // workgroup that got the upper half of the LDS sleeps for about half a column (2 cycles per key); its successors keep
-    // the offset.
-    if ((int)blockIdx.x < a.stagger) {
-        uint32_t la;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
-        if ((la & 0xfffu) != 0u)
-            for (int i = 0; i < n; i += 4096) __builtin_amdgcn_s_sleep(127);
     }
     SORT_PROBE(0);
     // ---- 0. the column (registers past the end hold a copy of a real key: harmless for min / max, and they stay out of
@@ -867,34 +857,10 @@ static int launch_rank4_items(SortArgs a, int ncols, hipStream_t st) {
     return check_launch("rank_match4_kernel");
 }
 
-int device_cu_count();
-
-// OPTEX_SORT_STAGGER=1 switches the first-generation stagger on (measured: +1.3 % at 16384 keys, -1 % at 12544: the
-// workgroups of a CU drift apart by themselves)
-static int stagger_enabled() {
-    static const int v = [] {
-        const char* e = getenv("OPTEX_SORT_STAGGER");
-        return (e && e[0] == '1') ? 1 : 0;
-    }();
-    return v;
-}
-
-// OPTEX_SORT_EXTRA_NT=0: 6400-key columns on 1024 threads x 7 keys instead of 640 x 10 (measurements)
-static int extra_nt_enabled() {
-    static const int v = [] {
-        const char* e = getenv("OPTEX_SORT_EXTRA_NT");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    return v;
-}
-
 template <int MODE>
-static int launch_rank4(const SortArgs& a0, int ncols, hipStream_t st) {
+static int launch_rank4_mode(const SortArgs& a0, int ncols, hipStream_t st) {
     SortArgs a = a0;
     const long n = a.n;
-    // two 1024-thread workgroups per CU for columns above 8192 keys; the smaller workgroups of shorter columns come four
-    // and eight to a CU and drift apart by themselves
-    a.stagger = (stagger_enabled() && n > 8192 && ncols > 2 * device_cu_count()) ? 2 * device_cu_count() : 0;
     // Workgroup size and keys per thread, always exactly ceil(n / threads) keys (the kernel relies on it: only the last
     // register row can be ragged).  Measured at [64, 256, n] (profiles/r02_sort_rank4_shapes.md): a column wants 6 .. 10
     // keys per thread — shorter register chains, no spills — as long as that leaves the CU its 32 wavefronts: 4096 keys
@@ -918,7 +884,7 @@ static int launch_rank4(const SortArgs& a0, int ncols, hipStream_t st) {
     // 6400 keys (a pass size of the 512^2 schedule) fill 640 threads x 10 keys exactly, three workgroups to a CU.  (Tried
     // and slower: 9216 keys on 576 x 16, three workgroups of nine wavefronts to a CU, 822 us against 573 us on 1024 x 9;
     // 12544 keys on 896 x 14, 936 us against 826 us on 1024 x 13.)
-    if (n == 10 * 640 && extra_nt_enabled()) return launch_rank4_items<10, 640, MODE>(a, ncols, st);
+    if (n == 10 * 640) return launch_rank4_items<10, 640, MODE>(a, ncols, st);
     switch ((int)((n + 1023) / 1024)) {
         case 6: return launch_rank4_items<6, 1024, MODE>(a, ncols, st);
         case 7: return launch_rank4_items<7, 1024, MODE>(a, ncols, st);
@@ -934,15 +900,8 @@ static int launch_rank4(const SortArgs& a0, int ncols, hipStream_t st) {
     }
 }
 
-int launch_rank_match4(int items, const SortArgs& a, int ncols, hipStream_t st) {
-    (void)items;
-    return launch_rank4<SORT_MATCH>(a, ncols, st);
-}
-
-// optex_sort_columns on the same kernel (keys and / or indices by rank): called by launch_sort_items<ITEMS, SORT_EMIT>
-int launch_rank_emit4(int items, const SortArgs& a, int ncols, hipStream_t st) {
-    (void)items;
-    return launch_rank4<SORT_EMIT>(a, ncols, st);
+int launch_rank4(int mode, const SortArgs& a, int ncols, hipStream_t st) {
+    return mode == SORT_MATCH ? launch_rank4_mode<SORT_MATCH>(a, ncols, st) : launch_rank4_mode<SORT_EMIT>(a, ncols, st);
 }
 
 }  // namespace optex

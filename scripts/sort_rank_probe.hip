@@ -1,17 +1,7 @@
-// Diagnostic (not part of the library): per-phase wall-clock breakdown of rank_match4_kernel (-DRANK=3: rank_match3_kernel),
-// two workgroups per CU like in the library.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DOPTEX_SORT_PROBE scripts/sort_rank3_probe.hip \
-//         optimaltextures_amd/csrc/api.hip -o /tmp/sort3_probe && /tmp/sort3_probe [n] [ns]
-#ifndef RANK
-#define RANK 4
-#endif
-#if RANK == 4
+// Diagnostic (not part of the library): per-phase wall-clock breakdown of rank_match4_kernel, workgroups per CU as in the
+// library.  Built by scripts/Makefile (-DOPTEX_SORT_PROBE):  make -C scripts sort_rank_probe.bin && scripts/sort_rank_probe.bin [n] [ns]
 #include "../optimaltextures_amd/csrc/sort_rank4.hip"
-#define LAUNCH optex::launch_rank_match4
-#else
-#include "../optimaltextures_amd/csrc/sort_rank3.hip"
-#define LAUNCH optex::launch_rank_match3
-#endif
+#define LAUNCH(items, a, ncols, st) optex::launch_rank4(optex::SORT_MATCH, a, ncols, st)
 
 #include <algorithm>
 #include <random>

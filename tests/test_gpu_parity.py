@@ -293,36 +293,26 @@ def test_sort_match_pass_sizes_bit_exact(dev, nt, ns):
         assert biteq(out[i], orc.sort_match(t[i], s[0]))
 
 
-@pytest.mark.parametrize("path", ["rank3", "rank2", "radix"])
-def test_sort_match_alternate_kernels_bit_exact(dev, path):
-    """the kernels behind the default one stay selectable (OPTEX_SORT_PATH, read once per process: a child process) and
-    stay exact: the integer-key owner-ranked kernel (csrc/sort_rank3.hip), the slot-ranked one (sort_rank2.hip) and the
-    plain radix kernel, on the edge distributions + a gaussian batch, against the oracle"""
-    import subprocess
-    import sys
-    code = r"""
-import sys, numpy as np, torch
-sys.path[:0] = [%r, %r]
-from test_gpu_parity import _sort_edge_columns, biteq, cu
-from optimaltextures_amd import ops
-from optimaltextures_amd.ops import Seg
-from oracle import oracle as orc
-dev = torch.device("cuda:0")
-for nt, ns in [(5000, 3100), (16384, 12288), (9216, 9216)]:
-    rng = np.random.default_rng(nt + ns)
+@pytest.mark.parametrize("nt,ns", [(300, 200), (2000, 1500), (4000, 4096), (8000, 5000), (12000, 12288), (16384, 12288)])
+def test_sort_radix_sweep_every_instantiation(dev, nt, ns):
+    """the LSD radix kernel behind the ranking kernel (csrc/sort.hip) at each of its keys-per-thread instantiations: every
+    column carries a NaN / an infinity, so the fast path flags it and the sweep sorts it (below RK_MIN_N = 512 keys the
+    radix kernel is the only path).  Match and emit, against the oracle, NaNs included (IEEE totalOrder)."""
+    rng = np.random.default_rng(nt * 3 + ns)
     names, t = _sort_edge_columns(nt, rng)
-    keep = [i for i, k in enumerate(names) if k != "with_inf_nan"]
-    t = t[keep]
-    s = (rng.standard_normal((1, len(keep), ns)) * 2 + 1).astype(np.float32)
+    t = t.copy()
+    t[:, nt // 3] = np.float32(np.inf)
+    t[::2, nt // 2] = np.float32(np.nan)
+    t[1::2, nt // 5] = -np.float32(np.inf)
+    s = (rng.standard_normal((1, t.shape[0], ns)) * 2 + 1).astype(np.float32)
     out = ops.sort_match_seg(Seg.of(cu(t[None], dev)), Seg.of(cu(s, dev))).cpu().numpy()[0]
     want = orc.sort_match(t, s[0])
-    for c, i in enumerate(keep):
-        assert biteq(out[c], want[c]), (nt, names[i])
-print("ok")
-""" % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, OPTEX_SORT_PATH=path)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for c, name in enumerate(names):
+        assert biteq(out[c], want[c]), (nt, name)
+    keys, idx = ops.sort_columns(cu(t[None], dev))
+    wk, wi = orc.sort_columns(t)
+    assert biteq(keys.cpu().numpy()[0], wk)
+    assert np.array_equal(idx.cpu().numpy()[0].astype(np.int64), wi.astype(np.int64))
 
 
 def _ulp_clusters(n, rng):
