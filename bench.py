@@ -165,6 +165,40 @@ def _cpu_texture(enc, dec, style, table, sizes, hist_mode, orc, seed=0):
     return pastiche
 
 
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def dry_run(args, rank, world, device):
+    """the launch path without the GPU work: every rank walks its rotation groups / texture indices step by step, the timed
+    region is bracketed by the same barrier + max-over-ranks reduction as the real run"""
+    B = args.batch
+    mine = []
+    t0 = time.perf_counter()
+    for k in range(args.warmup + args.steps):
+        group = k * world + rank
+        if k >= args.warmup:
+            mine.append([group * B, group * B + B])
+    otdist.barrier()
+    elapsed = otdist.all_reduce_max(time.perf_counter() - t0, device)
+    firsts = otdist.all_gather_floats(float(mine[0][0]) if mine else -1.0, device)
+    if rank == 0:
+        print(json.dumps({"metric": "512^2 textures/sec (relu3_1, default iters)", "value": None, "unit": "textures/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "dry_run": True,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "dry run: launch path only", "textures_per_gpu_per_step": B,
+                                     "parallelism": f"textures x{world}"},
+                          "first_timed_texture_by_rank": [int(f) for f in firsts], "textures_total": B * world * args.steps,
+                          "barrier_s": round(elapsed, 4)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,7 +213,16 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
     ap.add_argument("--no_miopen_find", action="store_true", help="torch.backends.cudnn.benchmark = False: MIOpen picks the convolution kernels from its heuristics / find-db instead of timing every solver in the warm-up step")
+    ap.add_argument("--seed", type=int, default=0, help="job seed: texture i's noise and its rotation group's sequence are functions of (seed, i) only (dist.py)")
+    ap.add_argument("--dry_run", action="store_true",
+                    help="no GPU work: join the process group (gloo on CPU), walk the steps' texture shards, exercise the "
+                         "barrier / max-over-ranks timing and print the JSON line with value null (tests of the N > 1 launch path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as `python bench.py --gpus N` (no launcher): become the launcher — one rank per GPU under
+        # torch.distributed.run on this node, which re-runs this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+        raise SystemExit(spawn_ranks(args.gpus))
 
     rank_env, world_env, _ = otdist.env_world()
     if world_env > 1:
@@ -189,23 +232,31 @@ def main():
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/optex_miopen_cache_rank{rank_env}")
         for d in (os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_CUSTOM_CACHE_DIR"]):
             os.makedirs(d, exist_ok=True)
-    rank, world, device = otdist.init_distributed()
+    rank, world, device = otdist.init_distributed("gloo" if args.dry_run and not torch.cuda.is_available() else None)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, rank, world, device)
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.backends.cudnn.benchmark = not args.no_miopen_find  # MIOpen find mode: the VGG convs are the largest non-hot-path cost
 
     B = args.batch
     style = synthetic_style(device)
     tex = make_texturizer(args.hist_mode, device)
-    tex.rng = np.random.RandomState(1000 + rank)  # one rotation sequence per rank and step, shared by its B textures
     if world > 1:
-        tex.style_sync = otdist.StyleSync(device)  # rank 0 encodes the style, RCCL broadcast per (pass, layer)
-    gen = torch.Generator(device=device).manual_seed(rank)
+        tex.style_sync = otdist.StyleSync(device)  # rank 0 encodes the style, ONE packed RCCL broadcast per forward call
+    # Seeding rule of sharded jobs (optimaltextures_amd/dist.py): textures are numbered globally; the B textures of one step of
+    # one rank are ROTATION GROUP q = step * world + rank (textures q*B .. q*B + B - 1): their noise comes from per-texture
+    # generators, their shared rotation sequence from RandomState(rotation_seed(seed, q)) — texture i is the same image
+    # whatever the number of GPUs.
+    counter = {"step": 0}
 
     def step(model):
-        pastiche = torch.rand((B, 3, SIZE, SIZE), device=device, generator=gen)
+        q = counter["step"] * world + rank
+        counter["step"] += 1
+        model.rng = otdist.rotation_rng(args.seed, q)
+        pastiche = otdist.texture_noise(q * B, B, (3, SIZE, SIZE), device, seed=args.seed)
         return model.forward(pastiche, [style])
 
     with torch.inference_mode():
@@ -243,7 +294,7 @@ def main():
                                f"5 passes 256..512, 52 OT iterations (default iters=500), hist_mode={args.hist_mode}, "
                                "style 736x512 synthetic, random-init VGG weights",
                    "textures_per_gpu_per_step": B, "hist_mode": args.hist_mode, "parallelism": f"textures x{world}",
-                   "rotation_sharing": "one sequence per rank and step"},
+                   "rotation_sharing": f"one sequence per rotation group of {B} textures (= one rank's step), seeded by the group's global number"},
     }
     traffic, traffic_source = pmc_traffic()
     if traffic_source:
@@ -267,7 +318,6 @@ def main():
         with torch.inference_mode():
             for mode in [m for m in args.other_modes.split(",") if m in ("cdf", "sort", "chol", "pca", "sym") and m != args.hist_mode]:
                 m = make_texturizer(mode, device)
-                m.rng = np.random.RandomState(1000)
                 step(m)  # warm-up (MIOpen/rocSOLVER handles)
                 torch.cuda.synchronize()
                 if mode == "sort" and not args.no_kernel_timing:
@@ -304,7 +354,6 @@ def main():
             with torch.inference_mode():
                 for mode in dict.fromkeys([args.hist_mode, "chol"]):
                     m = make_texturizer(mode, device, fuse_rotations=True)
-                    m.rng = np.random.RandomState(1000)
                     step(m)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
@@ -318,7 +367,6 @@ def main():
             # distribution (histmatch.py:11,17-18) — not like-for-like with the headline's independent textures
             with torch.inference_mode():
                 m = make_texturizer("chol", device, no_pca=False, independent=False)
-                m.rng = np.random.RandomState(1000)
                 step(m)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -339,9 +387,10 @@ def main():
                 for mode in dict.fromkeys([args.hist_mode, "sort", "chol"]):
                     m = OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode=mode, no_pca=True, layers=(LAYER,),
                                        independent=True, models_dir=models).to(device).eval()
-                    m.rng = np.random.RandomState(1000)
                     for timed in (False, True):
-                        pastiche = torch.rand((B, 3, SIZE, SIZE), device=device, generator=gen)
+                        m.rng = otdist.rotation_rng(args.seed, counter["step"])
+                        pastiche = otdist.texture_noise(counter["step"] * B, B, (3, SIZE, SIZE), device, seed=args.seed)
+                        counter["step"] += 1
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
                         out = m.forward(pastiche, [real_style])

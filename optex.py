@@ -80,8 +80,12 @@ def main(argv=None):
     rank, world, device = otdist.init_distributed()
     if device.type != "cuda":
         raise SystemExit("optex.py needs an MI355X: the HIP path has no CPU fallback")
+    # One seeding rule for sharded runs (optimaltextures_amd/dist.py): every rank seeds torch and numpy identically — all
+    # ranks then share one rotation stream and one mixing mask, as the reference's single process does (optex.py:149,
+    # 253-254) — and with --independent texture i's noise comes from its own generator, texture_seed(seed, i): the job
+    # writes the same images on 1, 2, 4 or 8 GPUs.
     if args.seed is not None:
-        torch.manual_seed(args.seed + rank)
+        torch.manual_seed(args.seed)
     if args.np_seed is not None:
         np.random.seed(args.np_seed)
 
@@ -95,12 +99,13 @@ def main(argv=None):
         if len(styles) > 1:
             assert styles[0].shape == styles[1].shape, "Style images must have the same shape"
         content = maybe_load_content(content_file, size=args.size, device=device, memory_format=memory_format)
-        if world > 1 and args.independent and args.batch < world:
-            # a rank with an empty shard would hand a (0, 3, H, W) pastiche to the kernels and abort the whole job
-            raise SystemExit(f"--independent over {world} ranks needs --batch >= {world} (got {args.batch})")
         lo, hi = otdist.shard_range(args.batch, rank, world) if (world > 1 and args.independent) else (0, args.batch)
-        shape = content.shape if content is not None else (hi - lo, 3, args.size, args.size)
-        pastiche = torch.rand(shape).to(device=device, memory_format=memory_format)
+        if content is None and args.independent and args.seed is not None:
+            pastiche = otdist.texture_noise(lo, hi - lo, (3, args.size, args.size), device, seed=args.seed, on_cpu=True)
+            pastiche = pastiche.contiguous(memory_format=memory_format)
+        else:  # the reference's draw (optex.py:263-265)
+            shape = content.shape if content is not None else (hi - lo, 3, args.size, args.size)
+            pastiche = torch.rand(shape).to(device=device, memory_format=memory_format)
 
         texturizer = OptimalTexture(
             size=args.size, iters=args.iters, passes=args.passes, hist_mode=args.hist_mode,
@@ -119,9 +124,12 @@ def main(argv=None):
         torch.cuda.synchronize()
         if rank == 0:
             print("Took:", time() - t)
-    if world > 1:
-        args.output_dir = f"{args.output_dir.rstrip('/')}/rank{rank}"
-    paths = save_image(pastiche, args)
+    if world > 1 and args.independent:
+        paths = save_image(pastiche, args, first=lo, total=args.batch)   # one directory, files numbered by global texture index
+    else:
+        if world > 1:  # pooled batch or content image: every rank holds the whole (replicated) job
+            args.output_dir = f"{args.output_dir.rstrip('/')}/rank{rank}"
+        paths = save_image(pastiche, args)
     print("\n".join(paths))
     return paths
 

@@ -46,18 +46,19 @@ def _padded(numel: int) -> int:
 class StyleSync:
     """Hook for OptimalTexture.style_sync: rank `src` owns the style side of a forward call, everyone gets it back.
 
-    One exchange = TWO messages whatever the number of tensors: a fixed-size int64 header (tensor count, shapes, and any
-    integers that travel along, e.g. feature-map sizes) and ONE flat fp32 payload holding every tensor back to back.
-    The header is the only host synchronisation of the receiving ranks (the PCA rank k is data dependent, so shapes
-    cannot be known in advance); the payload broadcast is issued asynchronously — over RCCL it runs on the
-    communicator's own stream and the consumers' stream merely waits for it — and the received tensors are views into
-    the flat buffer."""
+    One exchange = TWO messages whatever the number of tensors: an int64 header (tensor count, shapes, and any integers
+    that travel along, e.g. feature-map sizes) and ONE flat fp32 payload holding every tensor back to back.  The header is
+    the only host synchronisation of the receiving ranks (the PCA rank k is data dependent, so shapes cannot be known in
+    advance); the payload broadcast is issued asynchronously — over RCCL it runs on the communicator's own stream and the
+    consumers' stream merely waits for it — and the received tensors are views into the flat buffer.
 
-    MAX_TENSORS, MAX_INTS = 160, 320
-    HEADER = 3 + MAX_TENSORS * (1 + MAX_DIMS) + MAX_INTS
+    The header has no fixed capacity: it is sized from `counts = (n_tensors, n_ints)`, which the caller passes when every
+    rank can compute them (OptimalTexture.forward: 2 * passes * layers tensors); without `counts` a two-integer message
+    announces them first.  Nothing is checked on one rank only between collectives: a source whose lists do not match the
+    announced counts marks the header, the exchange completes, and EVERY rank raises."""
 
     def __init__(self, device, src: int = 0, group=None, always: bool = False):
-        """always=True: issue the two broadcasts even in a world of one (tests: the RCCL call sequence on one GPU)"""
+        """always=True: issue the broadcasts even in a world of one (tests: the RCCL call sequence on one GPU)"""
         self.device, self.src, self.group, self.always = torch.device(device), src, group, always
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -68,39 +69,67 @@ class StyleSync:
     def is_source(self) -> bool:
         return self.rank == self.src
 
-    def broadcast_packed(self, tensors: Optional[List[torch.Tensor]], ints: Optional[List[int]] = None):
-        """source: (list of fp32 tensors, list of ints) -> everyone: (list of tensors, list of ints)"""
+    @staticmethod
+    def header_len(n_tensors: int, n_ints: int) -> int:
+        return 3 + n_tensors * (1 + MAX_DIMS) + n_ints
+
+    def broadcast_packed(self, tensors: Optional[List[torch.Tensor]], ints: Optional[List[int]] = None,
+                         counts: Optional[Tuple[int, int]] = None):
+        """source: (list of fp32 tensors, list of ints) -> everyone: (list of tensors, list of ints).
+        counts = (n_tensors, n_ints) if known on every rank (saves the announcing message)."""
         if self.world == 1 and not self.always:
             return list(tensors), list(ints or [])
-        header = torch.zeros(self.HEADER, dtype=torch.int64)
+        if self.is_source:
+            ints = [int(v) for v in (ints or [])]
+            tensors = list(tensors or [])
+        if counts is None:
+            meta = torch.zeros(2, dtype=torch.int64)
+            if self.is_source:
+                meta[0], meta[1] = len(tensors), len(ints)
+            meta = meta.to(self.device)
+            dist.broadcast(meta, self.src, group=self.group)
+            n_t, n_i = (int(v) for v in meta.tolist())
+            self.messages += 1
+            self.bytes_moved += 16
+        else:
+            n_t, n_i = int(counts[0]), int(counts[1])
+        hlen = self.header_len(n_t, n_i)
+        header = torch.zeros(hlen, dtype=torch.int64)
         flat = None
         if self.is_source:
-            ints = list(ints or [])
-            assert tensors is not None and len(tensors) <= self.MAX_TENSORS and len(ints) <= self.MAX_INTS
-            header[0], header[1] = len(tensors), len(ints)
-            for i, t in enumerate(tensors):
-                assert t.dim() <= MAX_DIMS and t.dtype == torch.float32
-                base = 3 + i * (1 + MAX_DIMS)
-                header[base] = t.dim()
-                for d, sz in enumerate(t.shape):
-                    header[base + 1 + d] = sz
-            header[2] = sum(_padded(t.numel()) for t in tensors)
-            if ints:
-                header[3 + self.MAX_TENSORS * (1 + MAX_DIMS):3 + self.MAX_TENSORS * (1 + MAX_DIMS) + len(ints)] = torch.tensor(ints)
-            flat = torch.empty(int(header[2]), dtype=torch.float32, device=self.device)
-            off = 0
-            for t in tensors:  # every tensor starts on a 256-byte boundary: the kernels' 16-byte vector paths stay usable
-                flat[off:off + t.numel()].copy_(t.reshape(-1))
-                off += _padded(t.numel())
+            ok = (len(tensors) == n_t and len(ints) == n_i and
+                  all(t.dim() <= MAX_DIMS and t.dtype == torch.float32 for t in tensors))
+            if not ok:
+                header[0] = -1  # every rank raises after the exchange: no rank is left waiting in a collective
+            else:
+                header[0], header[1] = n_t, n_i
+                for i, t in enumerate(tensors):
+                    base = 3 + i * (1 + MAX_DIMS)
+                    header[base] = t.dim()
+                    for d, sz in enumerate(t.shape):
+                        header[base + 1 + d] = sz
+                header[2] = sum(_padded(t.numel()) for t in tensors)
+                if ints:
+                    header[3 + n_t * (1 + MAX_DIMS):] = torch.tensor(ints, dtype=torch.int64)
+                flat = torch.empty(int(header[2]), dtype=torch.float32, device=self.device)
+                off = 0
+                for t in tensors:  # every tensor starts on a 256-byte boundary: the kernels' 16-byte vector paths stay usable
+                    flat[off:off + t.numel()].copy_(t.reshape(-1))
+                    off += _padded(t.numel())
         header = header.to(self.device)
         dist.broadcast(header, self.src, group=self.group)
         h = header.tolist()  # the one host synchronisation of a receiving rank
-        n_t, n_i, total = h[0], h[1], h[2]
+        self.messages += 1
+        self.bytes_moved += hlen * 8
+        if h[0] < 0:
+            raise ValueError(f"StyleSync.broadcast_packed: the source rank's lists do not match the announced counts "
+                             f"({n_t} tensors, {n_i} ints) or hold a non-fp32 / >{MAX_DIMS}-d tensor")
+        total = h[2]
         if flat is None:
             flat = torch.empty(total, dtype=torch.float32, device=self.device)
         work = dist.broadcast(flat, self.src, group=self.group, async_op=True) if total else None
-        self.messages += 2 if total else 1
-        self.bytes_moved += total * 4 + self.HEADER * 8
+        self.messages += 1 if total else 0
+        self.bytes_moved += total * 4
         out, off = [], 0
         for i in range(n_t):
             base = 3 + i * (1 + MAX_DIMS)
@@ -112,11 +141,47 @@ class StyleSync:
             off += _padded(numel)
         if work is not None:
             work.wait()  # RCCL: the current stream waits for the communicator's stream, the host does not block
-        ibase = 3 + self.MAX_TENSORS * (1 + MAX_DIMS)
+        ibase = 3 + n_t * (1 + MAX_DIMS)
         return out, h[ibase:ibase + n_i]
 
     def __call__(self, payload: Optional[List[torch.Tensor]]) -> List[torch.Tensor]:
         return self.broadcast_packed(payload)[0]
+
+
+# ------------------------------------------------------------------------------------------------ seeding rule of sharded jobs
+# Independent textures are numbered globally (texture i of a job, whatever rank synthesises it).  Everything random about
+# texture i is a function of (seed, i) alone, so that a job gives the same images on 1, 2, 4 or 8 GPUs:
+#   * its noise initialisation comes from a generator seeded texture_seed(seed, i);
+#   * rotations: textures that share one rotation sequence (the reference shares R across its batch, optex.py:168-170)
+#     form a ROTATION GROUP of `group_size` consecutive textures, group q draws from RandomState(rotation_seed(seed, q));
+#     a rank always processes whole groups.  group_size = 1 gives every texture its own sequence (the reference run as
+#     separate B = 1 jobs).
+NOISE_STRIDE = 1_000_003
+
+
+def texture_seed(seed: int, index: int) -> int:
+    return (int(seed) * NOISE_STRIDE + int(index)) % (1 << 63)
+
+
+def rotation_seed(seed: int, group: int) -> int:
+    return (1000 + int(seed) * 7919 + int(group)) % (1 << 32)  # numpy's legacy RandomState takes 32-bit seeds
+
+
+def texture_noise(first: int, count: int, chw, device, seed: int = 0, on_cpu: bool = False) -> torch.Tensor:
+    """uniform [0, 1) noise images of textures first .. first + count - 1: [count, *chw] on `device`.  on_cpu=True draws
+    from a CPU generator and moves the result (what the reference CLI does, optex.py:263-265); otherwise the device's."""
+    gdev = torch.device("cpu") if on_cpu else torch.device(device)
+    g = torch.Generator(device=gdev)
+    out = torch.empty((count, *chw), dtype=torch.float32, device=device)
+    for j in range(count):
+        g.manual_seed(texture_seed(seed, first + j))
+        out[j].copy_(torch.rand(tuple(chw), generator=g, device=gdev), non_blocking=True)
+    return out
+
+
+def rotation_rng(seed: int, group: int):
+    import numpy as np
+    return np.random.RandomState(rotation_seed(seed, group))
 
 
 def barrier():

@@ -215,13 +215,15 @@ class OptimalTexture(torch.nn.Module):
             style_eigvs.append(eigvecs)
         return style_features, style_eigvs, style_hw
 
-    def _sync_style_sides(self, sides):
-        """sides: list of (resized, features, eigvecs, hw) known on the source rank (None elsewhere) -> the same list on
-        every rank.  ONE packed broadcast for all of them (dist.StyleSync.broadcast_packed): two messages and one host
-        synchronisation per call, whatever the number of passes and layers."""
+    def _sync_style_sides(self, sides, n_sides: int):
+        """sides: list of n_sides (resized, features, eigvecs, hw) known on the source rank (None elsewhere) -> the same
+        list on every rank.  ONE packed broadcast for all of them (dist.StyleSync.broadcast_packed): two messages and one
+        host synchronisation per call, whatever the number of passes and layers — the header is sized from the tensor
+        count, which every rank knows (2 per (pass, layer))."""
         if self.style_sync is None:
             return sides
         n_enc = len(self.encoders)
+        counts = (2 * n_sides * n_enc, 1 + n_sides * (1 + 2 * n_enc))
         tensors, ints = None, None
         if self.style_sync.is_source:
             tensors, ints = [], [len(sides)]
@@ -230,7 +232,7 @@ class OptimalTexture(torch.nn.Module):
                 for f, e, (h, w) in zip(sf, eig, hw):
                     tensors += [f, e]
                     ints += [h, w]
-        tensors, ints = self.style_sync.broadcast_packed(tensors, ints)
+        tensors, ints = self.style_sync.broadcast_packed(tensors, ints, counts=counts)
         out, ti, ii = [], 0, 1
         for _ in range(ints[0]):
             resized = bool(ints[ii])
@@ -250,7 +252,7 @@ class OptimalTexture(torch.nn.Module):
         rank encodes / fits, everyone receives the result"""
         need = self.style_sync is None or self.style_sync.is_source
         side = [(False,) + self._compute_style_side(style_tens)] if need else None
-        return self._sync_style_sides(side)[0][1:]
+        return self._sync_style_sides(side, 1)[0][1:]
 
     def prefetch_style_sides(self, pastiche_hw, styles: List[Tensor], content: Optional[Tensor]):
         """The style side of EVERY pass, before the first one starts.  It depends on the pastiche only through its
@@ -268,7 +270,7 @@ class OptimalTexture(torch.nn.Module):
             if resized:
                 hw = (get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True) if content is not None
                       else (size, size))
-        return self._sync_style_sides(sides if need else None)
+        return self._sync_style_sides(sides if need else None, self.passes)
 
     def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int,
                       style_side=None):

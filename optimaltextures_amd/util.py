@@ -111,13 +111,16 @@ def output_name(args) -> str:
     return "_".join(parts)
 
 
-def save_image(output: Tensor, args) -> list:
+def save_image(output: Tensor, args, first: int = 0, total: int = None) -> list:
+    """first / total (extension): `output` holds textures first .. first + len(output) - 1 of a job of `total` (a rank's
+    shard): files are numbered by the texture's GLOBAL index, so a sharded job writes the same file names as one process"""
     os.makedirs(args.output_dir, exist_ok=True)
     stem = output_name(args)
     paths = []
+    many = (total if total is not None else len(output)) > 1
     for o, out in enumerate(output):
         arr = out.detach().clamp(0, 1).mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
-        path = os.path.join(args.output_dir, stem + (f"_{o + 1}" if len(output) > 1 else "") + ".png")
+        path = os.path.join(args.output_dir, stem + (f"_{first + o + 1}" if many else "") + ".png")
         Image.fromarray(arr).save(path)
         paths.append(path)
     return paths

@@ -74,6 +74,33 @@ def _style_sync_job(rank, world, device):
     return out, sync.bytes_moved, otdist.all_reduce_max(float(rank + 1), device)
 
 
+def _style_sync_counts_job(rank, world, device):
+    """the header has no fixed capacity (2 * passes * layers tensors overflowed a 160-tensor header on the source
+    rank only and left the others waiting): 400 tensors in one exchange, counts known on every rank -> 2 messages;
+    a source whose lists do not match the announced counts makes EVERY rank raise, after the exchange"""
+    sync = otdist.StyleSync(device)
+    g = torch.Generator().manual_seed(7)
+    many = [torch.rand(2, 3, generator=g) for _ in range(400)] if sync.is_source else None
+    ints = list(range(901)) if sync.is_source else None
+    got, gi = sync.broadcast_packed(many, ints, counts=(400, 901))
+    msgs = sync.messages
+    raised = False
+    try:
+        sync.broadcast_packed([torch.zeros(1)] if sync.is_source else None, [1] if sync.is_source else None, counts=(2, 1))
+    except ValueError:
+        raised = True
+    # still in step: a third exchange works on both ranks
+    again, _ = sync.broadcast_packed([torch.full((4,), 2.5)] if sync.is_source else None, [] if sync.is_source else None)
+    return float(sum(t.sum() for t in got)), len(got), gi[-1], msgs, raised, again[0].tolist()
+
+
+def test_style_sync_unbounded_header_and_symmetric_errors_gloo_world2():
+    res = run_world(_style_sync_counts_job, 2)
+    assert res[0] == res[1]
+    total, n, last, msgs, raised, again = res[0]
+    assert n == 400 and last == 900 and msgs == 2 and raised and again == [2.5] * 4
+
+
 def test_style_sync_broadcast_gloo_world2():
     res = run_world(_style_sync_job, 2)
     (a, bytes_a, max_a), (b, bytes_b, max_b) = res[0], res[1]
@@ -180,14 +207,15 @@ def _bench_step_job(rank, world, device):
     from optimaltextures_amd.driver import OptimalTexture
     _oracle_backed_ops()
     tex = OptimalTexture(size=288, iters=20, passes=2, hist_mode="cdf", no_pca=True, layers=(1,), independent=True).eval()
-    tex.rng = np.random.RandomState(1000 + rank)
     if world > 1:
         tex.style_sync = otdist.StyleSync(device)
     g = torch.Generator().manual_seed(77)
     style = torch.rand(1, 3, 64, 96, generator=g)
     if world > 1 and rank != 0:
         style = torch.zeros_like(style)          # only the source rank's style may matter
-    pastiche = torch.rand(2, 3, 288, 288, generator=torch.Generator().manual_seed(rank))
+    # bench.py's seeding rule: this rank's step 0 is rotation group `rank` = textures 2 * rank, 2 * rank + 1
+    tex.rng = otdist.rotation_rng(0, rank)
+    pastiche = otdist.texture_noise(2 * rank, 2, (3, 288, 288), device, seed=0)
     with torch.inference_mode():
         out = tex.forward(pastiche, [style])
     sync = tex.style_sync
@@ -213,8 +241,76 @@ def _single_rank1_job(rank, world, device):
     from optimaltextures_amd.driver import OptimalTexture
     _oracle_backed_ops()
     tex = OptimalTexture(size=288, iters=20, passes=2, hist_mode="cdf", no_pca=True, layers=(1,), independent=True).eval()
-    tex.rng = np.random.RandomState(1001)
+    tex.rng = otdist.rotation_rng(0, 1)
     style = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(77))
-    pastiche = torch.rand(2, 3, 288, 288, generator=torch.Generator().manual_seed(1))
+    pastiche = otdist.texture_noise(2, 2, (3, 288, 288), device, seed=0)
     with torch.inference_mode():
         return tex.forward(pastiche, [style]).numpy().copy()
+
+
+# ------------------------------------------------------------------------------------------------ one seeding rule (dist.py)
+def _seeded_job(rank, world, device):
+    """a job of 4 rotation groups x 2 textures, sharded over `world` ranks by bench.py's rule (group q of step k on rank r:
+    q = k * world + r): returns {global texture index: image}"""
+    from optimaltextures_amd.driver import OptimalTexture
+    _oracle_backed_ops()
+    tex = OptimalTexture(size=288, iters=12, passes=2, hist_mode="cdf", no_pca=True, layers=(1,), independent=True).eval()
+    if world > 1:
+        tex.style_sync = otdist.StyleSync(device)
+    style = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(77))
+    B, groups, out = 2, 4, {}
+    with torch.inference_mode():
+        for k in range(groups // world):
+            q = k * world + rank
+            tex.rng = otdist.rotation_rng(5, q)
+            img = tex.forward(otdist.texture_noise(q * B, B, (3, 288, 288), device, seed=5), [style]).numpy()
+            for j in range(B):
+                out[q * B + j] = img[j].copy()
+    return out
+
+
+def test_texture_i_is_the_same_image_whatever_the_world_size():
+    one = run_world(_seeded_job, 1)[0]
+    two = run_world(_seeded_job, 2)
+    merged = {**two[0], **two[1]}
+    assert sorted(one) == sorted(merged) == list(range(8))
+    assert sorted(two[0]) == [0, 1, 4, 5] and sorted(two[1]) == [2, 3, 6, 7]
+    for i in range(8):
+        assert np.array_equal(one[i], merged[i]), i
+    assert not np.array_equal(one[0], one[1]) and not np.array_equal(one[0], one[2])
+
+
+def test_seed_helpers_are_pure_functions_of_seed_and_index():
+    a = otdist.texture_noise(3, 2, (3, 8, 8), "cpu", seed=1)
+    b = otdist.texture_noise(4, 1, (3, 8, 8), "cpu", seed=1)
+    assert torch.equal(a[1], b[0]) and not torch.equal(a[0], a[1])
+    assert not torch.equal(otdist.texture_noise(4, 1, (3, 8, 8), "cpu", seed=2)[0], b[0])
+    assert otdist.rotation_seed(0, 3) != otdist.rotation_seed(0, 4) and 0 <= otdist.rotation_seed(10 ** 6, 10 ** 7) < 2 ** 32
+    r1, r2 = otdist.rotation_rng(0, 3), otdist.rotation_rng(0, 3)
+    assert r1.standard_normal() == r2.standard_normal()
+
+
+# ------------------------------------------------------------------------------------------------ bench.py --gpus N launches itself
+def test_bench_gpus2_spawns_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must start two ranks itself and report
+    n_gpus = 2 (it used to benchmark ONE GPU with a warning).  --dry_run: the launch path only, gloo on CPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "8", "--dry_run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                              # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["steps"] == 3 and d["warmup"] == 1
+    assert d["textures_total"] == 8 * 2 * 3
+    assert d["first_timed_texture_by_rank"] == [16, 24]           # step 1 (after one warm-up step): groups 2 and 3
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry_run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)

@@ -26,11 +26,22 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 sync = otdist.StyleSync(dev, always=True)
 g = torch.Generator(device=dev).manual_seed(1)
 payload = [torch.rand(1, 11, 40, device=dev, generator=g), torch.rand(32, 11, device=dev, generator=g), torch.empty(0, 0, device=dev)]
-got, ints = sync.broadcast_packed(payload, [8, 12, 5])
+got, ints = sync.broadcast_packed(payload, [8, 12, 5], counts=(3, 3))
 assert ints == [8, 12, 5] and len(got) == 3
 for a, b in zip(got, payload):
     assert a.shape == b.shape and bool((a == b).all())
-assert sync.messages == 2 and sync.bytes_moved > 0
+assert sync.messages == 2 and sync.bytes_moved > 0        # counts known on every rank: header + payload
+got, ints = sync.broadcast_packed(payload, [8, 12, 5])
+assert ints == [8, 12, 5] and len(got) == 3 and sync.messages == 5   # + the announcing message
+# more tensors than any fixed header would hold (ADVICE r2: --passes >= 17 with five layers), still two messages
+many = [torch.rand(3, 7, device=dev, generator=g) for _ in range(2 * 20 * 5)]
+got, ints = sync.broadcast_packed(many, list(range(1 + 20 * 11)), counts=(200, 221))
+assert len(got) == 200 and ints[-1] == 220 and all(bool((a == b).all()) for a, b in zip(got, many))
+try:
+    sync.broadcast_packed(payload, [1], counts=(2, 1))        # wrong announcement: EVERY rank raises, after the exchange
+    raise SystemExit("expected ValueError")
+except ValueError:
+    pass
 otdist.barrier()
 assert otdist.all_reduce_max(3.5, dev) == 3.5
 assert otdist.all_gather_floats(1.25, dev) == [1.25]
@@ -48,6 +59,26 @@ def run(hook):
     return tex.forward(past, [style], None)
 a, b = run(False), run(True)
 assert bool((a == b).all()), float((a - b).abs().max())
+# BASELINE config 4's per-GPU shard: 8 independent 512^2 textures, relu3_1, C = 256 (no_pca), the full 5-pass schedule
+# (52 OT iterations), the style side arriving through the RCCL broadcast hook — bit for bit what the same shard gives
+# without the hook
+def shard(hook, mode):
+    import numpy as np
+    tex = OptimalTexture(size=512, iters=500, passes=5, hist_mode=mode, no_pca=True, layers=(3,), independent=True).to(dev).eval()
+    tex.rng = otdist.rotation_rng(0, 3)
+    if hook:
+        tex.style_sync = otdist.StyleSync(dev, always=True)
+    style = torch.rand(1, 3, 736, 512, generator=torch.Generator().manual_seed(5)).to(dev)
+    past = otdist.texture_noise(24, 8, (3, 512, 512), dev, seed=0)
+    with torch.inference_mode():
+        out = tex.forward(past, [style], None)
+    return out, (tex.style_sync.messages if hook else 0)
+for mode in ("cdf", "chol"):
+    (a, _), (b, msgs) = shard(False, mode), shard(True, mode)
+    assert a.shape == (8, 3, 512, 512) and bool(torch.isfinite(a).all())
+    assert bool((a == b).all()), (mode, float((a - b).abs().max()))
+    assert msgs == 2, msgs                                   # one packed exchange for all five passes
+    assert not bool((a[0] == a[1]).all())                    # independent textures
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("ok")

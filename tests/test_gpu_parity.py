@@ -664,6 +664,46 @@ def test_ot_loop_vs_oracle_bit_exact(dev, mode, S, Ss, C, n, ns, blend):
         assert biteq(got[s], w), f"segment {s}"
 
 
+@pytest.mark.parametrize("mode,C,blend", [("cdf", 256, False), ("sort", 256, False), ("cdf", 256, True), ("chol", 256, True),
+                                           ("cdf", 181, False), ("sort", 181, True), ("chol", 181, False)])
+def test_ot_loop_at_the_bench_shape_vs_oracle(dev, mode, C, blend):
+    """optex_ot_loop at the shape bench.py times: 8 independent 128 x 128 segments, 256 channels
+    (and the ragged PCA rank 181), style 128 x 96, 2 iterations — the launch that selects the hot-loop GEMM with the
+    row-statistics epilogue and the matcher fed from its partials — against the oracle chain on two sampled segments:
+    bit-exact for cdf / sort, by tolerance for chol."""
+    from optimaltextures_amd import ops
+    S, n, ns, iters = 8, 16384, 12288, 2
+    rng = np.random.default_rng(C + len(mode) + blend)
+    x = relu_feat(rng, S, C, n, scale=2.0, shift=0.3)
+    sty = relu_feat(rng, 1, C, ns, scale=1.5, shift=0.5)
+    content = relu_feat(rng, S, C, n, scale=2.0) if blend else None
+    lr = orc.LegacyRNG(C)
+    R = np.stack([orc.random_rotation(C, lr) for _ in range(iters)]).astype(np.float32)
+    Rt = np.ascontiguousarray(R.transpose(0, 2, 1))
+    xd = cu(x, dev)
+    ops.ot_loop(mode, xd, cu(sty, dev), cu(R, dev), cu(Rt, dev), content=cu(content, dev) if blend else None,
+                strength=0.05 if blend else 0.0)
+    got = xd.cpu().numpy()
+    assert np.isfinite(got).all()
+    for s in (1, 6):
+        w = x[s]
+        for it in range(iters):
+            rp, rs = orc.rotate_cm(w, R[it]), orc.rotate_cm(sty[0], R[it])
+            if mode == "cdf":
+                m = orc.cdf_match(rp, rs)
+            elif mode == "sort":
+                m = orc.sort_match(rp, rs)
+            else:
+                m = orc.linear_match(rp, 1, rs, 1, mode)
+            w = orc.unrotate_cm(m, R[it])
+            if blend:
+                w = orc.content_blend(w, content[s], 0.05)
+        if mode in ("cdf", "sort"):
+            assert biteq(got[s], w), f"{mode} C={C} segment {s}: {np.count_nonzero(got[s] != w)} elements differ"
+        else:
+            assert maxrel(got[s], w) <= 2 * LIN_TOL, f"{mode} C={C} segment {s}: {maxrel(got[s], w):.2e}"
+
+
 # ================================================================================================ full-size (BASELINE) properties
 def test_full_size_relu3_1_step_vs_oracle(dev):
     """BASELINE config shape: relu3_1 at the 512 pass, C = 256, n = 128*128, style 128x96 — one whole cdf step bit-exact
