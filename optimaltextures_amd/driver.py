@@ -129,7 +129,7 @@ def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content:
         ops.rotate_seg(style, R32[it], out=ys)      # optex.py:171
         mu_t, cov_t = ops.linear_stats(Seg.of(y), pool=False)    # histmatch.py:16-18
         mu_s, cov_s = ops.linear_stats(Seg.of(ys), pool=False)   # histmatch.py:20-22
-        tt = transfer_operator(cov_t, cov_s, hist_mode).mT.contiguous()  # histmatch.py:24-42
+        tt = transfer_operator(cov_t, cov_s, hist_mode, eps=1.0).mT.contiguous()  # histmatch.py:24-42 (eps * I added above)
         ops.gemm_tn(tt, y, m, c, c, n, s, lda=c, at_ss=c * c, ldb=n, b_ss=c * n, ldo=n, o_ss=c * n, bsub=mu_t, bsub_ss=c,
                     badd=mu_s, badd_ss=c if ss == s else 0)          # histmatch.py:27/34/42,44
         ops.unrotate_seg(m, Rt32[it], out=x, content=content, strength=strength)  # optex.py:175 + 115-117

@@ -31,8 +31,12 @@ def _spd_sqrt_pair(cov: Tensor):
     return (v * r.unsqueeze(-2)) @ v.mT, (v / r.unsqueeze(-2)) @ v.mT
 
 
-def transfer_operator(cov_t: Tensor, cov_s: Tensor, mode: str, eps: float = 1.0) -> Tensor:
-    """T with matched = T @ hist_t (histmatch.py:24-42); cov_* are [..., C, C] (batched over independent segments)."""
+def transfer_operator(cov_t: Tensor, cov_s: Tensor, mode: str, eps: float = 0.0) -> Tensor:
+    """T with matched = T @ hist_t (histmatch.py:24-42); cov_* are [..., C, C] symmetric positive definite (batched over
+    independent segments).  eps is NOT added here: it is a known LOWER BOUND of both spectra — the eps of a
+    `cov + eps * I` the caller formed — and only tunes the scaling of the Newton-Schulz square roots (pca / sym).  The
+    default 0 means "unknown" (the bound is then taken from the matrix norm, slower convergence but always safe); a bound
+    larger than the true smallest eigenvalue would give a wrong root, so pass it only where eps * I was really added."""
     if mode not in LINEAR_MODES:
         raise ValueError(f"unknown linear mode {mode!r}")
     c = cov_t.shape[-1]

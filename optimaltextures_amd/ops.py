@@ -170,9 +170,10 @@ def spd_sqrt(a, lambda_min=0.0):
     return y, z
 
 
-def transfer_operator_t(cov_t, cov_s, mode, eps=1.0):
-    """T^T per segment (the `At` operand of the apply GEMM): cov_t [S, C, C], cov_s [1 or S, C, C], eps * I included
-    (histmatch.py:24-42)"""
+def transfer_operator_t(cov_t, cov_s, mode, eps=0.0):
+    """T^T per segment (the `At` operand of the apply GEMM): cov_t [S, C, C], cov_s [1 or S, C, C] symmetric positive
+    definite (histmatch.py:24-42).  eps: a known lower bound of both spectra (the eps of `cov + eps * I` when the caller
+    added it, as linear_stats does); 0 = unknown, always safe"""
     lib = _lib.lib()
     cov_t, cov_s = _f32c(cov_t).contiguous(), _f32c(cov_s).contiguous()
     s, c, _ = cov_t.shape

@@ -102,10 +102,11 @@ def test_transfer_operator_vs_oracle(dev, mode, C, S, Ss):
     s = relu_feat(rng, Ss, C, ns, scale=1.5, shift=0.5)
     _, cov_t = ops.linear_stats(Seg.of(cu(t, dev)), pool=False)
     _, cov_s = ops.linear_stats(Seg.of(cu(s, dev)), pool=False)
-    Tt = ops.transfer_operator_t(cov_t, cov_s, mode).cpu().numpy()
-    for i in range(S):
-        _, T = orc.linear_match(t[i], 1, s[i if Ss > 1 else 0], 1, mode, return_T=True)
-        assert np.abs(Tt[i].T - T).max() <= 2e-5 * max(np.abs(T).max(), 1.0), f"segment {i}"
+    for eps in (0.0, 1.0):  # spectrum bound unknown (the public default) / the eps * I that linear_stats added
+        Tt = ops.transfer_operator_t(cov_t, cov_s, mode, eps).cpu().numpy()
+        for i in range(S):
+            _, T = orc.linear_match(t[i], 1, s[i if Ss > 1 else 0], 1, mode, return_T=True)
+            assert np.abs(Tt[i].T - T).max() <= 2e-5 * max(np.abs(T).max(), 1.0), f"segment {i} eps {eps}"
 
 
 @pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
