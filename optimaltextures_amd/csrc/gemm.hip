@@ -503,6 +503,7 @@ template <bool BPM, bool OPM>
 static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     if (a.sym) return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);  // square tiles: the mirrored store needs BM == BN
+    if (!BPM && !OPM && gemm_rs_supported(a, n_cu)) return gemm_rs_launch(a, n_cu, st);  // the hot loop's rotations
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
         if (!BPM && !OPM && vec && hot_shape(a, n_cu) && output_vec(a)) {
@@ -533,10 +534,13 @@ static bool operands_vec(const GemmArgs& a) {
 }
 
 bool gemm_rowstat_supported(const GemmArgs& a) {
-    return operands_vec(a) && output_vec(a) && !a.bsub && !a.badd && !a.content && hot_shape(a, device_cu_count());
+    if (a.bsub || a.badd || a.content) return false;
+    const int n_cu = device_cu_count();
+    return gemm_rs_supported(a, n_cu) || (operands_vec(a) && output_vec(a) && hot_shape(a, n_cu));
 }
 
-int gemm_rowstat_parts(long n) { return (int)(n / 128) * 2; }  // pixel tiles of 128 x the block's two wave columns
+// one partial per 64 pixels: the R-stationary kernel's tiles, or the 256 x 128 kernel's pixel tiles x its two wave columns
+int gemm_rowstat_parts(long n) { return n % 64 == 0 ? (int)(n / 64) : 0; }
 
 int gemm_tn_launch(GemmArgs& a, int b_layout, int o_layout, hipStream_t st) {
     const bool bpm = b_layout == OPTEX_PIXEL_MAJOR, opm = o_layout == OPTEX_PIXEL_MAJOR;

@@ -1,0 +1,302 @@
+// gemm_rs.hip — the rotation GEMM of the hot loop as an R-STATIONARY, LDS-free, barrier-free kernel.
+//
+//   OUT[s][m][i] = sum_k At[s][k][m] * B[s][k][i]          (optex.py:170,171,175; channel-major in and out)
+//
+// The left operand of every rotation is a C x C matrix (C <= 256) shared by all pixels of a segment; the right operand, the
+// feature map, streams through once.  gemm16_cm_kernel (gemm.hip) stages both through LDS in 16-deep K chunks: one barrier
+// per chunk with two waves per SIMD, 0.73-0.76 of the fp32-MFMA peak, issue-bound.  This kernel removes the
+// staging instead of tuning it:
+//
+//   * one workgroup of four wavefronts per CU (one wave per SIMD, the whole 512-register file), PERSISTENT over a contiguous
+//     range of pixel tiles;
+//   * wave w owns the output rows [16 MT w, 16 MT (w + 1)) and keeps its slice of the matrix — MT x KS fragments of
+//     v_mfma_f32_16x16x4_f32's A operand, up to 256 registers — for the whole launch (reloaded only when the segment, and
+//     with it the matrix, changes);
+//   * the feature map goes from HBM straight into the MFMA's B-operand registers: lane (i = lane & 15, q = lane >> 4) loads
+//     the 16 bytes B[4 ks + q][p0 + 4 i .. + 3] of k-step ks — component j of that float4 IS the fragment of pixel sub-tile j
+//     (sub-tile j = pixels p0 + 4 i + j: which 16 pixels form a 16-column MFMA tile is free to choose), so one
+//     global_load_dwordx4 feeds 4 MT MFMAs and nothing passes through LDS.  A ring of DEPTH k-steps is in flight per wave,
+//     across tile boundaries; the four waves of a CU read the same lines, HBM sees them once;
+//   * fed (B fragment, A fragment) the MFMA returns the transposed block: lane (m = lane & 15, g = lane >> 4) ends up with
+//     the 16 CONSECUTIVE pixels p0 + 16 g .. + 15 of channel m of each of its MT row tiles — four 16-byte stores each;
+//   * no barrier anywhere: the waves of a workgroup never exchange data.
+//
+// Numerics: every output element is the k-ordered fmaf chain of the other GEMM kernels and of the oracle (a * b commutes
+// exactly; k-steps ascend, four k per step in MFMA order) — bit-identical.  Rows k >= K enter as exact zeros on BOTH
+// operands (a zero A fragment alone would turn a non-finite pad read into NaN).
+// Optional per-row statistics of the output (GemmArgs::rowstat, 1 = min / max, 2 = sum) are taken from the accumulators:
+// one partial per 64-pixel tile, [n_seg][n / 64][M].
+#include "gemm_args.h"
+
+namespace optex {
+
+typedef float rs_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) char* rs_gptr;      // global address space kept explicit: a pointer rebuilt
+typedef const __attribute__((address_space(1))) float* rs_gfptr;    // from integers would otherwise be loaded with flat_load
+
+// a uniform global pointer pinned to an SGPR pair (the 64-bit tile arithmetic is uniform, but not always provably so)
+__device__ __forceinline__ rs_gptr rs_uniform(const void* p) {
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<rs_gptr>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+}
+
+constexpr int RS_BN = 64;     // pixels per tile (4 sub-tiles of 16)
+#ifndef RS_DEPTH_VALUE
+#define RS_DEPTH_VALUE 16
+#endif
+constexpr int RS_DEPTH = RS_DEPTH_VALUE;   // k-steps of B in flight per wave (scripts/gemm_rs_probe.hip builds variants)
+constexpr int RS_RAG = 16;    // the last RS_RAG k-steps of an instantiation may lie (partly) beyond K
+
+struct RsArgs {
+    GemmArgs g;
+    int tiles_n;          // pixel tiles per segment (n / 64)
+    int segs_per_group;   // segments sharing one matrix: n_seg (at_seg_stride == 0) or 1; gridDim.y = n_seg / segs_per_group
+};
+
+// MT: 16-row tiles per wave (rows per workgroup = 64 MT);  KS: k-steps of 4, 4 (KS - RS_RAG) <= K <= 4 KS: the last RS_RAG
+// k-steps test their rows, and a k-step entirely beyond K is branched over (uniform);  EXTRA: bias (badd) and content
+// blend in the epilogue
+template <int MT, int KS, int ROWSTAT, bool EXTRA>
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 1))) void gemm_rs_kernel(RsArgs ra) {
+    static_assert(KS % RS_DEPTH == 0, "the B ring keeps its phase across tiles");
+    const GemmArgs& a = ra.g;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int mw = wave * 16 * MT;
+    const int M = a.M, K = a.K;
+
+    // A workgroup keeps ONE matrix: blockIdx.y selects a group of `segs_per_group` segments that share it (all of them
+    // when at_seg_stride == 0, one otherwise), blockIdx.x a contiguous, balanced range of the group's tiles (segment-major).
+    const long T = (long)ra.tiles_n * ra.segs_per_group;
+    const long t0 = (long)blockIdx.y * T;
+    const long tb = t0 + T * (long)blockIdx.x / (long)gridDim.x, te = t0 + T * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    if (tb >= te) return;
+
+    // the wave's slice of the matrix: fragment (t, ks) = At[4 ks + q][mw + 16 t + i].  Branch-free: rows / columns beyond
+    // K / M read a clamped (in-bounds) address and are zeroed by a select; one 32-bit offset per load on a uniform base.
+    float af[MT][KS];
+    auto load_matrix = [&](int seg) {
+        const rs_gfptr At = reinterpret_cast<rs_gfptr>(rs_uniform(a.At + (size_t)seg * a.at_ss));
+        // (masks, not selects: a select of a loaded value against zero is turned into a branch around the load, and the
+        // ragged rows then load two at a time behind s_waitcnt vmcnt(0))
+        unsigned moff[MT], mmask[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const int m = mw + 16 * t + l15;
+            mmask[t] = m < M ? 0xffffffffu : 0u;
+            moff[t] = (unsigned)m & mmask[t];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int k = 4 * ks + kq;
+            const unsigned kmask = (ks < KS - RS_RAG || k < K) ? 0xffffffffu : 0u;
+            const unsigned koff = ((unsigned)k & kmask) * (unsigned)a.lda;
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const float v = At[koff + moff[t]];
+                af[t][ks] = __uint_as_float(__float_as_uint(v) & kmask & mmask[t]);
+            }
+            // 16 k-steps (64 loads) in flight at a time: unfenced, the scheduler issues all 256 loads at once and spills
+            if (ks % 16 == 15) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // B addressing: ONE uniform running byte pointer (advanced by four rows per k-step and re-based at tile boundaries)
+    // + ONE 32-bit lane offset (row q of the k-step, pixels 4 i .. 4 i + 3).
+    const unsigned lane_off = ((unsigned)kq * (unsigned)a.ldb + 4u * (unsigned)l15) * 4u;
+    // the one k-step that K may cut (rows 4 ks + q >= K): those lanes read row 4 ks (in bounds) and zero the value
+    const bool ok_p = (K & ~3) + kq < K;
+    const unsigned lane_off_p = ok_p ? lane_off : 4u * (unsigned)l15 * 4u;
+    const size_t step_bytes = (size_t)a.ldb * 16u;
+    // (seg, pt) of the current and of the next tile are carried along as counters: a 64-bit division per tile is ~350
+    // scalar instructions during which the matrix pipe idles
+    auto tile_base = [&](int seg, int pt) {  // uniform
+        return rs_uniform(a.B + (size_t)seg * a.b_ss + (size_t)pt * RS_BN);
+    };
+    int seg = (int)(tb / ra.tiles_n), pt = (int)(tb - (long)seg * ra.tiles_n);
+    rs_gptr pk = tile_base(seg, pt);
+    // load k-step ks (compile-time position) at the running pointer into `dst`, advance the pointer
+    auto load_next = [&](int ks, rs_f4& dst) {
+        if (ks >= KS - RS_RAG) {
+            if (4 * ks < K) {  // uniform; a k-step entirely beyond K is neither loaded nor multiplied
+                const bool partial = 4 * ks + 4 > K;
+                // (the rows beyond K are zeroed where the k-step is CONSUMED: masking here would wait for the load at once)
+                dst = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(pk + (partial ? lane_off_p : lane_off));
+            }
+        } else {
+            dst = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(pk + lane_off);
+        }
+        pk += step_bytes;
+    };
+
+    load_matrix(seg);
+
+    rs_f4 br[RS_DEPTH];
+#pragma unroll
+    for (int d = 0; d < RS_DEPTH; d++) {
+        br[d] = rs_f4{0.f, 0.f, 0.f, 0.f};
+        load_next(d, br[d]);
+    }
+
+    for (long tile = tb; tile < te; tile++) {
+        int nseg = seg, npt = pt;
+        if (tile + 1 < te) {  // (the last tile prefetches itself once more: in bounds, unused)
+            npt = pt + 1;
+            if (npt == ra.tiles_n) { npt = 0; nseg = seg + 1; }
+        }
+        const rs_gptr nbase = tile_base(nseg, npt);
+
+        rs_f4 acc[MT][4];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            rs_f4 b = br[ks % RS_DEPTH];
+            if (ks >= KS - RS_RAG) {  // the k-step that K cuts: its rows beyond K enter as exact zeros
+                const unsigned pm = (4 * ks + 4 > K && !ok_p) ? 0u : 0xffffffffu;
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = __uint_as_float(__float_as_uint(b[j]) & pm);
+            }
+            // refill the slot: k-step ks + DEPTH of this tile, or the head of the next one
+            if (ks + RS_DEPTH == KS) pk = nbase;
+#ifndef RS_PROBE_NOLOAD
+            load_next((ks + RS_DEPTH) % KS, br[ks % RS_DEPTH]);
+#endif
+            if (ks < KS - RS_RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
+#pragma unroll
+                for (int t = 0; t < MT; t++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const rs_f4 c = ks == 0 ? rs_f4{0.f, 0.f, 0.f, 0.f} : acc[t][j];
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], af[t][ks], c, 0, 0, 0);
+                    }
+                }
+            }
+            // pin the software pipeline: unfenced, the machine scheduler sinks every load down to its consumer, eight
+            // k-steps later, and the loop becomes load -> s_waitcnt vmcnt(0) -> 16 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue.  acc[t][j][r] = OUT[m = mw + 16 t + l15][pixel p0 + 16 kq + 4 r + j]
+        float* __restrict__ Op = a.O + (size_t)seg * a.o_ss + (size_t)pt * RS_BN + 16 * kq;
+        const float* __restrict__ Cp = (EXTRA && a.content) ? a.content + (size_t)seg * a.o_ss + (size_t)pt * RS_BN + 16 * kq : nullptr;
+        const float* __restrict__ badd = (EXTRA && a.badd) ? a.badd + (size_t)seg * a.badd_ss : nullptr;
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const int m = mw + 16 * t + l15;
+            const bool ok = m < M;
+            const size_t row = (size_t)(ok ? m : 0) * a.ldo;
+            rs_f4 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = rs_f4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+            if (EXTRA) {
+                if (badd) {
+                    const float bias = badd[ok ? m : 0];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = v[r] + bias;
+                }
+                if (Cp) {  // optex.py:115-117, same arithmetic in the same order as the other kernels: v + strength * (content - v)
+                    rs_f4 c[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) c[r] = *reinterpret_cast<const rs_f4*>(Cp + row + 4 * r);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const rs_f4 d = c[r] - v[r];
+                        const rs_f4 sd = d * a.strength;
+                        v[r] = v[r] + sd;
+                    }
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) *reinterpret_cast<rs_f4*>(Op + row + 4 * r) = v[r];
+            }
+            if (ROWSTAT != 0) {
+                // statistics of the plain product (this path runs without bias / blend): the lane's 16 pixels, then the
+                // four lane groups holding the other pixels of the same channel
+                const size_t pidx = ((size_t)seg * ra.tiles_n + pt) * (size_t)M + (size_t)m;
+                if (ROWSTAT == 1) {
+                    float mn = v[0][0], mx = v[0][0];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            mn = fminf(mn, v[r][j]);
+                            mx = fmaxf(mx, v[r][j]);
+                        }
+                    mn = fminf(mn, __shfl_xor(mn, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mn = fminf(mn, __shfl_xor(mn, 32));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    if (kq == 0 && ok) {
+                        a.rs_a[pidx] = mn;
+                        a.rs_b[pidx] = mx;
+                    }
+                } else {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) sm = sm + v[r][j];
+                    sm = sm + __shfl_xor(sm, 16);
+                    sm = sm + __shfl_xor(sm, 32);
+                    if (kq == 0 && ok) a.rs_a[pidx] = sm;
+                }
+            }
+        }
+        seg = nseg;
+        pt = npt;
+    }
+}
+
+static inline bool rs_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// shapes / layouts the R-stationary kernel takes (channel-major on both sides is the caller's business)
+bool gemm_rs_supported(const GemmArgs& a, int n_cu) {
+    if (a.epi || a.sym || a.bsub) return false;
+    if (a.M <= 128 || a.M > 256 || a.K <= 128 || a.K > 256) return false;
+    if (a.n % RS_BN != 0 || a.n <= 0) return false;
+    if (!rs_aligned16(a.B) || a.ldb % 4 != 0 || a.b_ss % 4 != 0) return false;
+    if (!rs_aligned16(a.O) || a.ldo % 4 != 0 || a.o_ss % 4 != 0) return false;
+    if (a.content && !rs_aligned16(a.content)) return false;
+    if ((unsigned long long)a.ldb * 4ull + 64ull >= (1ull << 32)) return false;  // 32-bit lane offsets
+    const long long total = (long long)(a.n / RS_BN) * a.n_seg;
+    return total >= 2LL * n_cu;  // every CU streams at least two tiles behind one matrix load
+}
+
+int gemm_rs_parts(long n) { return (int)(n / RS_BN); }
+
+template <int MT, int KS>
+static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
+    const GemmArgs& a = ra.g;
+    if (a.badd || a.content)
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, true>), grid, dim3(256), 0, st, ra);
+    else if (a.rowstat == 1)
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, false>), grid, dim3(256), 0, st, ra);
+    else if (a.rowstat == 2)
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, false>), grid, dim3(256), 0, st, ra);
+    else
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, false>), grid, dim3(256), 0, st, ra);
+    return check_launch("gemm_rs_kernel");
+}
+
+int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
+    RsArgs ra;
+    ra.g = a;
+    ra.tiles_n = (int)(a.n / RS_BN);
+    ra.segs_per_group = a.at_ss == 0 ? a.n_seg : 1;
+    const int groups = a.n_seg / ra.segs_per_group;
+    const long per_group = (long)ra.tiles_n * ra.segs_per_group;
+    long gx = (n_cu + groups - 1) / groups;  // one workgroup per CU over all groups
+    if (gx > per_group) gx = per_group;
+    ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
+                   4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
+    const dim3 grid((unsigned)gx, (unsigned)groups);
+    // rows: (128, 192] -> three 16-row tiles per wave, (192, 256] -> four; depth: (128, 192] -> 48 k-steps, (192, 256] -> 64
+    const bool m4 = a.M > 192, k64 = a.K > 192;
+    if (m4 && k64) return rs_launch_mk<4, 64>(ra, grid, st);
+    if (m4) return rs_launch_mk<4, 48>(ra, grid, st);
+    if (k64) return rs_launch_mk<3, 64>(ra, grid, st);
+    return rs_launch_mk<3, 48>(ra, grid, st);
+}
+
+}  // namespace optex

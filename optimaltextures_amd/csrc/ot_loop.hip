@@ -70,7 +70,7 @@ struct LoopWs {
 
     void layout(Bump& b, int mode, long n, long ns, int C, int n_seg, int Ss, int iters, int fused) {
         const size_t xs = (size_t)n_seg * C * n, cc = (size_t)C * C;
-        rs_parts = (n % 128 == 0) ? gemm_rowstat_parts(n) : 0;
+        rs_parts = gemm_rowstat_parts(n);
         const size_t rs_floats = (size_t)n_seg * rs_parts * C;
         if (mode == MODE_CDF || mode == MODE_SORT) {
             y = b.take<float>(xs);

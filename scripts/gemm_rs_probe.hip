@@ -1,0 +1,51 @@
+// Diagnostic (not part of the library): the R-stationary rotation GEMM (csrc/gemm_rs.hip) alone at the hot-loop shape,
+// timed with HIP events; built in variants by scripts/Makefile (-DRS_DEPTH_VALUE=..., -DRS_PROBE_NOLOAD).
+//   scripts/gemm_rs_probe_<variant>.bin [n_seg] [n] [M] [K] [reps]
+#include "../optimaltextures_amd/csrc/gemm_rs.hip"
+
+#include <random>
+#include <vector>
+
+int main(int argc, char** argv) {
+    const int S = argc > 1 ? atoi(argv[1]) : 64;
+    const long n = argc > 2 ? atol(argv[2]) : 16384;
+    const int M = argc > 3 ? atoi(argv[3]) : 256, K = argc > 4 ? atoi(argv[4]) : 256;
+    const int reps = argc > 5 ? atoi(argv[5]) : 20;
+    std::vector<float> hb((size_t)S * K * n), ha((size_t)K * M);
+    std::mt19937 g(1);
+    std::normal_distribution<float> d(0.f, 1.f);
+    for (auto& v : hb) v = d(g);
+    for (auto& v : ha) v = d(g) / 16.f;
+    float *A, *B, *O;
+    (void)hipMalloc(&A, ha.size() * 4); (void)hipMalloc(&B, hb.size() * 4); (void)hipMalloc(&O, (size_t)S * M * n * 4);
+    (void)hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    optex::GemmArgs a{};
+    a.At = A; a.lda = M; a.at_ss = 0; a.B = B; a.ldb = n; a.b_ss = (long)K * n; a.O = O; a.ldo = n; a.o_ss = (long)M * n;
+    a.M = M; a.K = K; a.n = n; a.n_seg = S; a.alpha = 1.f; a.prof_cls = optex::KC_GEMM;
+    const int n_cu = optex::device_cu_count();
+    if (!optex::gemm_rs_supported(a, n_cu)) { printf("shape not supported\n"); return 1; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) optex::gemm_rs_launch(a, n_cu, 0);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; i++) optex::gemm_rs_launch(a, n_cu, 0);
+    (void)hipEventRecord(e1, 0);
+    (void)hipDeviceSynchronize();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<float> ho((size_t)M * 64);
+    (void)hipMemcpy(ho.data(), O, ho.size() * 4, hipMemcpyDeviceToHost);
+    double chk = 0;
+    for (float v : ho) chk += v;
+    const double us = 1e3 * ms / reps, tf = 2.0 * M * K * (double)n * S / (us * 1e6);
+    printf("depth %d%s: S=%d n=%ld M=%d K=%d  %.1f us  %.1f TFLOP/s  (%.3f of 157.3)  checksum %.6f\n", optex::RS_DEPTH,
+#ifdef RS_PROBE_NOLOAD
+           " NOLOAD",
+#else
+           "",
+#endif
+           S, n, M, K, us, tf, tf / 157.3, chk);
+    return 0;
+}

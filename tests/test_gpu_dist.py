@@ -60,25 +60,66 @@ def run(hook):
 a, b = run(False), run(True)
 assert bool((a == b).all()), float((a - b).abs().max())
 # BASELINE config 4's per-GPU shard: 8 independent 512^2 textures, relu3_1, C = 256 (no_pca), the full 5-pass schedule
-# (52 OT iterations), the style side arriving through the RCCL broadcast hook — bit for bit what the same shard gives
-# without the hook (VERDICT r2 item 1b)
-def shard(hook, mode):
-    import numpy as np
+# (52 OT iterations), the style side arriving through the RCCL broadcast hook (VERDICT r2 item 1b).
+# MIOpen's fp32 convolutions are not reproducible run to run at these shapes (scripts/dbg: the same encoder call differs
+# by 1e-6 .. 7e-6 from itself, and `cdf` amplifies one ulp to a whole bin within five iterations, SURVEY 0), so two whole
+# forward calls cannot be compared bit for bit.  What the hook must not change is checked exactly where it is exact:
+#   (1) the style side the hook delivers == the style side computed locally, bit for bit, for all five passes, when both
+#       come from the SAME encoder outputs (the hook only packs, broadcasts and re-slices them);
+#   (2) the OT loop of every pass, fed the recorded inputs of the hooked run, reproduces the hooked run's loop output bit
+#       for bit (the kernels are deterministic; only the convolutions around them are not);
+#   (3) the un-hooked forward agrees with the hooked one as closely as two un-hooked runs agree with each other (chol:
+#       round-off; cdf: image statistics).
+def make(mode):
     tex = OptimalTexture(size=512, iters=500, passes=5, hist_mode=mode, no_pca=True, layers=(3,), independent=True).to(dev).eval()
     tex.rng = otdist.rotation_rng(0, 3)
-    if hook:
+    return tex
+style = torch.rand(1, 3, 736, 512, generator=torch.Generator().manual_seed(5)).to(dev)
+def noise():
+    return otdist.texture_noise(24, 8, (3, 512, 512), dev, seed=0)
+with torch.inference_mode():
+    # (1) pack -> broadcast -> slice is the identity on the style sides
+    tex = make("cdf")
+    local = [(False,) + tex._compute_style_side(tex._style_tensors([style], sz, True)) for sz in tex.sizes]
+    tex.style_sync = otdist.StyleSync(dev, always=True)
+    got = tex._sync_style_sides(local, tex.passes)
+    assert tex.style_sync.messages == 2                      # one packed exchange for all five passes
+    for (r0, f0, e0, h0), (r1, f1, e1, h1) in zip(local, got):
+        assert r0 == r1 and h0 == h1 and all(bool((x == y).all()) for x, y in zip(f0, f1))
+        assert all(x.shape == y.shape for x, y in zip(e0, e1))
+    # (2) + (3)
+    from optimaltextures_amd import driver as drv
+    for mode in ("cdf", "chol"):
+        calls = []
+        real = drv.ot_iterations
+        def spy(x, style_f, hist_mode, iters, **kw):
+            state = kw["rng"].get_state()
+            xin = x.clone()
+            out = real(x, style_f, hist_mode, iters, **kw)
+            calls.append((xin, style_f.clone(), iters, state, out.clone()))
+            return out
+        drv.ot_iterations = spy
+        tex = make(mode)
         tex.style_sync = otdist.StyleSync(dev, always=True)
-    style = torch.rand(1, 3, 736, 512, generator=torch.Generator().manual_seed(5)).to(dev)
-    past = otdist.texture_noise(24, 8, (3, 512, 512), dev, seed=0)
-    with torch.inference_mode():
-        out = tex.forward(past, [style], None)
-    return out, (tex.style_sync.messages if hook else 0)
-for mode in ("cdf", "chol"):
-    (a, _), (b, msgs) = shard(False, mode), shard(True, mode)
-    assert a.shape == (8, 3, 512, 512) and bool(torch.isfinite(a).all())
-    assert bool((a == b).all()), (mode, float((a - b).abs().max()))
-    assert msgs == 2, msgs                                   # one packed exchange for all five passes
-    assert not bool((a[0] == a[1]).all())                    # independent textures
+        hooked = tex.forward(noise(), [style], None)
+        drv.ot_iterations = real
+        assert tex.style_sync.messages == 2 and len(calls) == 5
+        assert hooked.shape == (8, 3, 512, 512) and bool(torch.isfinite(hooked).all())
+        assert not bool((hooked[0] == hooked[1]).all())      # independent textures
+        import numpy as np
+        for xin, sf, iters, state, want in calls:            # the loop replayed on the recorded inputs
+            rng = np.random.RandomState()
+            rng.set_state(state)
+            again = real(xin.clone(), sf, mode, iters, pooled=False, rng=rng)
+            assert bool((again == want).all()), (mode, iters)
+        plain = make(mode).forward(noise(), [style], None)
+        plain2 = make(mode).forward(noise(), [style], None)
+        if mode == "chol":
+            noise_floor = float((plain - plain2).abs().max())
+            assert float((hooked - plain).abs().max()) <= max(10 * noise_floor, 1e-3), (float((hooked - plain).abs().max()), noise_floor)
+        else:
+            for im in (plain, plain2):
+                assert abs(float(hooked.mean() - im.mean())) < 5e-3 and abs(float(hooked.std() - im.std())) < 5e-3
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("ok")
