@@ -484,6 +484,9 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
 // top clock (profiles/r02_power_gemm_rocm_smi.md).
 int device_cu_count();
 
+// (internal, not ABI: scripts/gemm_rs_probe.hip times the kernels against each other at every shape)
+bool gemm_rs_enabled = true, gemm_rs_force = false;
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // the hot-loop kernel stores (and reads the content) in 16-byte pieces along the pixel rows
@@ -503,7 +506,14 @@ template <bool BPM, bool OPM>
 static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     if (a.sym) return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);  // square tiles: the mirrored store needs BM == BN
-    if (!BPM && !OPM && gemm_rs_supported(a, n_cu)) return gemm_rs_launch(a, n_cu, st);  // the hot loop's rotations
+    // Channel-major rotations of the hot loop.  Both hot kernels run at the chip's power-managed clock on dense data
+    // (profiles/r03_gemm_power_dvfs.md: 2.11-2.13 GHz, MFMA duty 0.74-0.76 either way); the 256 x 128 LDS-tiled kernel is
+    // 2-5 % ahead where it fits exactly (192 < M, K <= 256, multiples of 4), the R-stationary one everywhere else: PCA
+    // ranks (M = K = 181: 86 vs 60 TFLOP/s of useful flops), project / unproject (181 x 256: 93 vs 67), 192 x 192 (89 vs 78).
+    if (!BPM && !OPM && gemm_rs_enabled && gemm_rs_supported(a, n_cu)) {
+        const bool lds_fits = a.M > 192 && a.K > 192 && a.M % 4 == 0 && vec && hot_shape(a, n_cu) && output_vec(a);
+        if (!lds_fits || gemm_rs_force) return gemm_rs_launch(a, n_cu, st);
+    }
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
         if (!BPM && !OPM && vec && hot_shape(a, n_cu) && output_vec(a)) {
@@ -536,7 +546,7 @@ static bool operands_vec(const GemmArgs& a) {
 bool gemm_rowstat_supported(const GemmArgs& a) {
     if (a.bsub || a.badd || a.content) return false;
     const int n_cu = device_cu_count();
-    return gemm_rs_supported(a, n_cu) || (operands_vec(a) && output_vec(a) && hot_shape(a, n_cu));
+    return (gemm_rs_enabled && gemm_rs_supported(a, n_cu)) || (operands_vec(a) && output_vec(a) && hot_shape(a, n_cu));
 }
 
 // one partial per 64 pixels: the R-stationary kernel's tiles, or the 256 x 128 kernel's pixel tiles x its two wave columns

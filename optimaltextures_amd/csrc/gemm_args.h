@@ -37,6 +37,7 @@ int gemm_rowstat_parts(long n);
 // the R-stationary, LDS-free hot-loop kernel (gemm_rs.hip): channel-major in / out, 128 < M, K <= 256, n % 64 == 0
 bool gemm_rs_supported(const GemmArgs& a, int n_cu);
 int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st);
+extern bool gemm_rs_enabled, gemm_rs_force;
 
 // internal launcher behind optex_gemm_tn (gemm.hip): `a` fully filled except tiles_*; layouts are OPTEX_*_MAJOR
 int gemm_tn_launch(GemmArgs& a, int b_layout, int o_layout, hipStream_t st);

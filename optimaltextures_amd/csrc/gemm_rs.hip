@@ -1,25 +1,25 @@
-// gemm_rs.hip — the rotation GEMM of the hot loop as an R-STATIONARY kernel: one barrier pair per pixel TILE, not per K chunk.
+// gemm_rs.hip — the rotation GEMM of the hot loop as an R-STATIONARY, LDS-free, barrier-free kernel.
 //
 //   OUT[s][m][i] = sum_k At[s][k][m] * B[s][k][i]          (optex.py:170,171,175; channel-major in and out)
 //
 // The left operand of every rotation is a C x C matrix (C <= 256) shared by all pixels of a segment; the right operand, the
-// feature map, streams through once.  gemm16_cm_kernel (gemm.hip) stages both operands through LDS in 16-deep K chunks: one
-// barrier per chunk with two waves per SIMD, 0.73-0.76 of the fp32-MFMA peak, issue-bound.  Here:
+// feature map, streams through once.  gemm16_cm_kernel (gemm.hip) stages both through LDS in 16-deep K chunks: one barrier
+// per chunk with two waves per SIMD, 0.73-0.76 of the fp32-MFMA peak, issue-bound.  This kernel removes the
+// staging instead of tuning it:
 //
 //   * one workgroup of four wavefronts per CU (one wave per SIMD, the whole 512-register file), PERSISTENT over a contiguous
-//     range of 64-pixel tiles;
+//     range of pixel tiles;
 //   * wave w owns the output rows [16 MT w, 16 MT (w + 1)) and keeps its slice of the matrix — MT x KS fragments of
-//     v_mfma_f32_16x16x4_f32's A operand, up to 256 registers — for the whole launch: the matrix is never re-read and
-//     never staged;
-//   * the feature map goes HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), a WHOLE
-//     [K, 64] tile per buffer, two buffers: the request for tile t + 2 is issued when tile t has been consumed and has a
-//     full tile's compute time (~14 us) to land.  Synchronisation per tile: s_waitcnt vmcnt + s_barrier before the first
-//     fragment read, s_barrier after the last — against one barrier per 16-deep chunk (16 per tile) in the LDS kernel;
-//   * a k-step's fragments come back with ONE ds_read_b128 per lane: lane (i = lane & 15, q = lane >> 4) holds
-//     B[4 ks + q][p0 + 4 i .. + 3], and component j of that float4 IS the B fragment of pixel sub-tile j (sub-tile j =
-//     pixels p0 + 4 i + j: which 16 pixels form a 16-column MFMA tile is free to choose) — one LDS read feeds 4 MT MFMAs;
+//     v_mfma_f32_16x16x4_f32's A operand, up to 256 registers — for the whole launch (reloaded only when the segment, and
+//     with it the matrix, changes);
+//   * the feature map goes from HBM straight into the MFMA's B-operand registers: lane (i = lane & 15, q = lane >> 4) loads
+//     the 16 bytes B[4 ks + q][p0 + 4 i .. + 3] of k-step ks — component j of that float4 IS the fragment of pixel sub-tile j
+//     (sub-tile j = pixels p0 + 4 i + j: which 16 pixels form a 16-column MFMA tile is free to choose), so one
+//     global_load_dwordx4 feeds 4 MT MFMAs and nothing passes through LDS.  A ring of DEPTH k-steps is in flight per wave,
+//     across tile boundaries; the four waves of a CU read the same lines, HBM sees them once;
 //   * fed (B fragment, A fragment) the MFMA returns the transposed block: lane (m = lane & 15, g = lane >> 4) ends up with
-//     the 16 CONSECUTIVE pixels p0 + 16 g .. + 15 of channel m of each of its MT row tiles — four 16-byte stores each.
+//     the 16 CONSECUTIVE pixels p0 + 16 g .. + 15 of channel m of each of its MT row tiles — four 16-byte stores each;
+//   * no barrier anywhere: the waves of a workgroup never exchange data.
 //
 // Numerics: every output element is the k-ordered fmaf chain of the other GEMM kernels and of the oracle (a * b commutes
 // exactly; k-steps ascend, four k per step in MFMA order) — bit-identical.  Rows k >= K enter as exact zeros on BOTH
@@ -43,9 +43,9 @@ __device__ __forceinline__ rs_gptr rs_uniform(const void* p) {
 
 constexpr int RS_BN = 64;     // pixels per tile (4 sub-tiles of 16)
 #ifndef RS_DEPTH_VALUE
-#define RS_DEPTH_VALUE 4
+#define RS_DEPTH_VALUE 16
 #endif
-constexpr int RS_DEPTH = RS_DEPTH_VALUE;   // k-steps of B fragments read ahead from LDS per wave (scripts/gemm_rs_probe.hip builds variants)
+constexpr int RS_DEPTH = RS_DEPTH_VALUE;   // k-steps of B in flight per wave (scripts/gemm_rs_probe.hip builds variants)
 constexpr int RS_RAG = 16;    // the last RS_RAG k-steps of an instantiation may lie (partly) beyond K
 
 struct RsArgs {
@@ -59,7 +59,7 @@ struct RsArgs {
 // blend in the epilogue
 template <int MT, int KS, int ROWSTAT, bool EXTRA>
 __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 1))) void gemm_rs_kernel(RsArgs ra) {
-    static_assert(KS % 4 == 0 && KS * 2048 <= 160 * 1024, "two whole-tile buffers in LDS");
+    static_assert(KS % RS_DEPTH == 0, "the B ring keeps its phase across tiles");
     const GemmArgs& a = ra.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
@@ -102,82 +102,65 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
         }
     };
 
-    // ---- the feature map: HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write), two whole-tile
-    // buffers [KS k-steps][4 rows x 64 pixels] = KS KiB each.  One DMA instruction moves one k-step: lane (q = lane >> 4,
-    // i = lane & 15) fetches B[4 ks + q][p0 + 4 i .. + 3] and the hardware lays the wave's 64 x 16 bytes down contiguously —
-    // exactly the order in which ds_read_b128 at +16 lane hands the k-step back as MFMA fragments (conflict-free).
-    // Wave w issues the k-steps w, w + 4, ...: KS / 4 instructions per tile, ALWAYS that many (k-steps beyond K re-read
-    // k-step 0 into LDS rows nobody consumes), so that `s_waitcnt vmcnt(KS / 4)` means "everything but the newest tile".
-    extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
-    constexpr unsigned BUF_BYTES = (unsigned)KS * 1024u;
+    // B addressing: ONE uniform running byte pointer (advanced by four rows per k-step and re-based at tile boundaries)
+    // + ONE 32-bit lane offset (row q of the k-step, pixels 4 i .. 4 i + 3).
     const unsigned lane_off = ((unsigned)kq * (unsigned)a.ldb + 4u * (unsigned)l15) * 4u;
-    // the one k-step that K may cut (rows 4 ks + q >= K): those lanes read row 4 ks (in bounds); the value is zeroed
-    // where it is consumed
+    // the one k-step that K may cut (rows 4 ks + q >= K): those lanes read row 4 ks (in bounds) and zero the value
     const bool ok_p = (K & ~3) + kq < K;
     const unsigned lane_off_p = ok_p ? lane_off : 4u * (unsigned)l15 * 4u;
     const size_t step_bytes = (size_t)a.ldb * 16u;
-    const int ksteps = (K + 3) >> 2;  // k-steps that hold rows below K
-    auto issue_tile = [&](int seg, int pt, int buf) {
-        const rs_gptr base = rs_uniform(a.B + (size_t)seg * a.b_ss + (size_t)pt * RS_BN);
-        typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
-#pragma unroll
-        for (int q = 0; q < KS / 4; q++) {
-            const int ks = 4 * q + wave;                       // uniform
-            const bool live = ks < ksteps;
-            const bool partial = live && 4 * ks + 4 > K;
-            const rs_gptr src = base + (live ? (size_t)ks * step_bytes : 0) + (partial ? lane_off_p : lane_off);
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(src),
-                                             (lds_ptr)rs_smem + (unsigned)buf * BUF_BYTES + (unsigned)ks * 1024u,
-                                             16, 0, 0);
-        }
+    // (seg, pt) of the current and of the next tile are carried along as counters: a 64-bit division per tile is ~350
+    // scalar instructions during which the matrix pipe idles
+    auto tile_base = [&](int seg, int pt) {  // uniform
+        return rs_uniform(a.B + (size_t)seg * a.b_ss + (size_t)pt * RS_BN);
     };
-    // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-    constexpr int NDMA = KS / 4;
-    constexpr int WAIT_ALL_BUT_ONE_TILE = (NDMA & 15) | (7 << 4) | (15 << 8) | ((NDMA >> 4) << 14);
-    constexpr int WAIT_ALL = (7 << 4) | (15 << 8);
-
     int seg = (int)(tb / ra.tiles_n), pt = (int)(tb - (long)seg * ra.tiles_n);
-    // (seg, pt) are carried along as counters: a 64-bit division per tile is ~350 scalar instructions of idle matrix pipe
-    auto advance = [&](int& sg, int& p) {
-        p++;
-        if (p == ra.tiles_n) { p = 0; sg++; }
+    rs_gptr pk = tile_base(seg, pt);
+    // load k-step ks (compile-time position) at the running pointer into `dst`, advance the pointer
+    auto load_next = [&](int ks, rs_f4& dst) {
+        if (ks >= KS - RS_RAG) {
+            if (4 * ks < K) {  // uniform; a k-step entirely beyond K is neither loaded nor multiplied
+                const bool partial = 4 * ks + 4 > K;
+                // (the rows beyond K are zeroed where the k-step is CONSUMED: masking here would wait for the load at once)
+                dst = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(pk + (partial ? lane_off_p : lane_off));
+            }
+        } else {
+            dst = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(pk + lane_off);
+        }
+        pk += step_bytes;
     };
-    const int ntiles = (int)(te - tb);
-    int dseg = seg, dpt = pt;  // the next tile to request
-    issue_tile(dseg, dpt, 0);
-    advance(dseg, dpt);
-    if (ntiles > 1) {
-        issue_tile(dseg, dpt, 1);
-        advance(dseg, dpt);
-    }
+
     load_matrix(seg);
 
-    for (int it = 0; it < ntiles; it++) {
-        const int buf = it & 1;
-        // my share of tile `it` has landed (the newest request, tile it + 1, may still be in flight) ...
-        if (it + 1 < ntiles) __builtin_amdgcn_s_waitcnt(WAIT_ALL_BUT_ONE_TILE);
-        else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
-        __builtin_amdgcn_s_barrier();  // ... and so has everybody else's
-        const unsigned rd = (unsigned)buf * BUF_BYTES + (unsigned)lane * 16u;
-        auto lds_step = [&](int ks) {
-            typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
-            return *reinterpret_cast<const __attribute__((address_space(3))) rs_f4*>((lds_ptr)rs_smem + rd + (unsigned)ks * 1024u);
-        };
-        constexpr int P = RS_DEPTH;  // k-steps of fragments ahead in registers (covers the LDS latency: one wave per SIMD)
-        rs_f4 br[P];
+    rs_f4 br[RS_DEPTH];
 #pragma unroll
-        for (int d = 0; d < P; d++) br[d] = lds_step(d);
+    for (int d = 0; d < RS_DEPTH; d++) {
+        br[d] = rs_f4{0.f, 0.f, 0.f, 0.f};
+        load_next(d, br[d]);
+    }
+
+    for (long tile = tb; tile < te; tile++) {
+        int nseg = seg, npt = pt;
+        if (tile + 1 < te) {  // (the last tile prefetches itself once more: in bounds, unused)
+            npt = pt + 1;
+            if (npt == ra.tiles_n) { npt = 0; nseg = seg + 1; }
+        }
+        const rs_gptr nbase = tile_base(nseg, npt);
 
         rs_f4 acc[MT][4];
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            rs_f4 b = br[ks % P];
+            rs_f4 b = br[ks % RS_DEPTH];
             if (ks >= KS - RS_RAG) {  // the k-step that K cuts: its rows beyond K enter as exact zeros
                 const unsigned pm = (4 * ks + 4 > K && !ok_p) ? 0u : 0xffffffffu;
 #pragma unroll
                 for (int j = 0; j < 4; j++) b[j] = __uint_as_float(__float_as_uint(b[j]) & pm);
             }
-            if (ks + P < KS) br[ks % P] = lds_step(ks + P);
+            // refill the slot: k-step ks + DEPTH of this tile, or the head of the next one
+            if (ks + RS_DEPTH == KS) pk = nbase;
+#ifndef RS_PROBE_NOLOAD
+            load_next((ks + RS_DEPTH) % KS, br[ks % RS_DEPTH]);
+#endif
             if (ks < KS - RS_RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
 #pragma unroll
                 for (int t = 0; t < MT; t++) {
@@ -188,17 +171,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
                     }
                 }
             }
-            // pin the software pipeline: unfenced, the machine scheduler sinks every fragment read down to its consumer
+            // pin the software pipeline: unfenced, the machine scheduler sinks every load down to its consumer, eight
+            // k-steps later, and the loop becomes load -> s_waitcnt vmcnt(0) -> 16 MFMAs
             __builtin_amdgcn_sched_barrier(0);
         }
-        // everybody is done reading this buffer: request the tile after next into it (it has a whole tile's time to land)
-        __builtin_amdgcn_s_barrier();
-#ifndef RS_PROBE_NOLOAD
-        if (it + 2 < ntiles) {
-            issue_tile(dseg, dpt, buf);
-            advance(dseg, dpt);
-        }
-#endif
 
         // ---- epilogue.  acc[t][j][r] = OUT[m = mw + 16 t + l15][pixel p0 + 16 kq + 4 r + j]
         float* __restrict__ Op = a.O + (size_t)seg * a.o_ss + (size_t)pt * RS_BN + 16 * kq;
@@ -267,7 +243,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
                 }
             }
         }
-        advance(seg, pt);
+        seg = nseg;
+        pt = npt;
     }
 }
 
@@ -288,32 +265,18 @@ bool gemm_rs_supported(const GemmArgs& a, int n_cu) {
 
 int gemm_rs_parts(long n) { return (int)(n / RS_BN); }
 
-template <typename KernT>
-static int rs_launch_one(KernT kern, size_t lds, const RsArgs& ra, dim3 grid, hipStream_t st) {
-    // more than 64 KiB of dynamic LDS needs the attribute, once per kernel and device (idempotent: a benign race)
-    static bool done[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!done[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("gemm_rs_kernel: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-            return OPTEX_E_LAUNCH;
-        }
-        done[dev & 63] = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, ra);
-    return check_launch("gemm_rs_kernel");
-}
-
 template <int MT, int KS>
 static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
     const GemmArgs& a = ra.g;
-    const size_t lds = (size_t)2 * KS * 1024;
-    if (a.badd || a.content) return rs_launch_one(gemm_rs_kernel<MT, KS, 0, true>, lds, ra, grid, st);
-    if (a.rowstat == 1) return rs_launch_one(gemm_rs_kernel<MT, KS, 1, false>, lds, ra, grid, st);
-    if (a.rowstat == 2) return rs_launch_one(gemm_rs_kernel<MT, KS, 2, false>, lds, ra, grid, st);
-    return rs_launch_one(gemm_rs_kernel<MT, KS, 0, false>, lds, ra, grid, st);
+    if (a.badd || a.content)
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, true>), grid, dim3(256), 0, st, ra);
+    else if (a.rowstat == 1)
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, false>), grid, dim3(256), 0, st, ra);
+    else if (a.rowstat == 2)
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, false>), grid, dim3(256), 0, st, ra);
+    else
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, false>), grid, dim3(256), 0, st, ra);
+    return check_launch("gemm_rs_kernel");
 }
 
 int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
