@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="independent textures per GPU per step (16 / 32 / 64 measured: 176 / 183 / 198 textures/s)")
     ap.add_argument("--hist_mode", type=str, default="cdf", choices=["cdf", "sort", "chol", "pca", "sym"])
-    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,refdefaults,assets",
+    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,pcadefault,ownrotations,refdefaults,assets",
                     help="one extra step each (N = 1 only); 'fused' = the labelled re-association fast paths, "
                          "'refdefaults' = chol + PCA + pooled batch (the reference's own defaults), 'assets' = the headline "
                          "configuration on the reference's real relu3_1 weights and style/graffiti.jpg (assets/)")
@@ -362,6 +362,42 @@ def main():
                     fused[mode] = round(B / (time.perf_counter() - t0), 3)
             result["textures_per_s_fused_rotations"] = fused.get(args.hist_mode)
             result["textures_per_s_fused_by_hist_mode"] = fused
+        if "pcadefault" in args.other_modes.split(","):
+            # the reference's default flags apart from the batch semantics: PCA ON (optex.py:109-110,119-120: C = k ~ 165-181
+            # at relu3_1, ragged: the rotations take the R-stationary GEMM, project / unproject too), independent textures
+            pcad = {}
+            with torch.inference_mode():
+                for mode in ("chol", "cdf"):
+                    m = make_texturizer(mode, device, no_pca=False)
+                    step(m)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    step(m)
+                    torch.cuda.synchronize()
+                    pcad[mode] = round(B / (time.perf_counter() - t0), 3)
+            result["textures_per_s_pca_default"] = {
+                "by_hist_mode": pcad, "config": f"PCA on (the reference's default), {B} independent textures per step, otherwise the headline configuration"}
+        if "ownrotations" in args.other_modes.split(","):
+            # un-shared rotations: every texture draws its own sequence from its own numpy stream (the reference run as B
+            # separate B = 1 jobs, optex.py:149,168) — nothing on the style side is shared either, and the host draws
+            # B x 52 x 32895 normals per step from sequential MT19937 streams (thread pool)
+            with torch.inference_mode():
+                m = make_texturizer(args.hist_mode, device)
+
+                def own_step():
+                    q = counter["step"]
+                    counter["step"] += 1
+                    m.rng = [otdist.rotation_rng(args.seed, q * B + j) for j in range(B)]
+                    return m.forward(otdist.texture_noise(q * B, B, (3, SIZE, SIZE), device, seed=args.seed), [style])
+
+                own_step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                own_step()
+                torch.cuda.synchronize()
+                result["textures_per_s_independent_rotations"] = {
+                    "value": round(B / (time.perf_counter() - t0), 3),
+                    "config": f"hist_mode={args.hist_mode}, one rotation sequence per texture (rotation group size 1), host threads for the numpy streams: {min(64, os.cpu_count() or 1)}"}
         if "refdefaults" in args.other_modes.split(","):
             # the reference's own defaults for this layer: hist_mode chol, PCA on, --batch POOLED into one
             # distribution (histmatch.py:11,17-18) — not like-for-like with the headline's independent textures

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 4
+#define OPTEX_ABI_VERSION 5
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -157,7 +157,11 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
  * Fused hot loop, optex.py:112-117, every iteration of a (pass, layer) enqueued by one call:
  *   for it in range(iters):  x = ((x @ R_it) matched-to (style @ R_it)) @ R_it^T ; optional content blend
  * x is [n_seg, C, n] channel-major segments (independent textures), updated in place; style is [src_n_seg, C, ns].
- * R32 / Rt32 are [iters, C, C] as produced by optex_rotations_from_normals.
+ * R32 / Rt32 are [iters, C, C] as produced by optex_rotations_from_normals, shared by all segments (r_seg_stride = 0: the
+ *   reference shares one R across its batch, optex.py:168-170), or one set per segment, R32 + s * r_seg_stride (ABI 5:
+ *   r_seg_stride >= iters * C * C elements; the reference run once per image draws its own rotations every time).  With
+ *   per-segment rotations nothing on the style side is shared either: every segment is matched to its own rotated copy
+ *   of the style.  Implemented for modes 0 / 1 with fuse_rotations = 0 (OPTEX_E_UNSUPPORTED otherwise).
  * mode: 0 = cdf, 1 = sort, 2 = chol, 3 = pca, 4 = sym (histmatch.py:5 `mode`; eps = 1 as every caller leaves it).
  *   The linear modes (2-4) take the style's mean and covariance ONCE per call and rotate them as C x C matrices
  *   (cov(S R) = R^T cov(S) R — the style-feature statistics the multi-GPU path broadcasts); the pastiche side is the
@@ -174,9 +178,9 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
  *     cov(x R) = R^T cov(x) R: one covariance + one feature-map GEMM per iteration instead of three.
  * ------------------------------------------------------------------------------------------------- */
 size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters,
-                              int fuse_rotations);
+                              int fuse_rotations, long r_seg_stride);
 int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
-                  const float* R32, const float* Rt32, int iters, const float* content, float strength,
+                  const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content, float strength,
                   int fuse_rotations, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------

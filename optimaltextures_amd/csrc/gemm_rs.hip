@@ -56,8 +56,9 @@ struct RsArgs {
 
 // MT: 16-row tiles per wave (rows per workgroup = 64 MT);  KS: k-steps of 4, 4 (KS - RS_RAG) <= K <= 4 KS: the last RS_RAG
 // k-steps test their rows, and a k-step entirely beyond K is branched over (uniform);  EXTRA: bias (badd) and content
-// blend in the epilogue
-template <int MT, int KS, int ROWSTAT, bool EXTRA>
+// blend in the epilogue (1), and the operand centring `B[k][i] - bsub[k]` of the linear modes' apply step as well (2:
+// KS more registers, one subtraction per fragment component, the same single rounding as the other kernels)
+template <int MT, int KS, int ROWSTAT, int EXTRA>
 __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 1))) void gemm_rs_kernel(RsArgs ra) {
     static_assert(KS % RS_DEPTH == 0, "the B ring keeps its phase across tiles");
     const GemmArgs& a = ra.g;
@@ -131,12 +132,24 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
     };
 
     load_matrix(seg);
+    // EXTRA == 2: the centring value bsub[4 ks + q] of every k-step travels through the ring beside its fragment (one more
+    // dword load per k-step, L1 / L2 resident; KS registers of it kept for the whole launch spill).  The launcher keeps a
+    // workgroup inside one segment when bsub varies with the segment.
+    const rs_gfptr sub = EXTRA == 2 ? reinterpret_cast<rs_gfptr>(rs_uniform(a.bsub + (size_t)seg * a.bsub_ss)) : nullptr;
+    float bsr[EXTRA == 2 ? RS_DEPTH : 1];
+    auto load_sub = [&](int ks, float& dst) {
+        if (EXTRA == 2) {
+            const int k = 4 * ks + kq;
+            dst = sub[(ks < KS - RS_RAG || k < K) ? k : 0];
+        }
+    };
 
     rs_f4 br[RS_DEPTH];
 #pragma unroll
     for (int d = 0; d < RS_DEPTH; d++) {
         br[d] = rs_f4{0.f, 0.f, 0.f, 0.f};
         load_next(d, br[d]);
+        load_sub(d, bsr[EXTRA == 2 ? d : 0]);
     }
 
     for (long tile = tb; tile < te; tile++) {
@@ -151,6 +164,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             rs_f4 b = br[ks % RS_DEPTH];
+            if (EXTRA == 2) b = b - bsr[EXTRA == 2 ? ks % RS_DEPTH : 0];
             if (ks >= KS - RS_RAG) {  // the k-step that K cuts: its rows beyond K enter as exact zeros
                 const unsigned pm = (4 * ks + 4 > K && !ok_p) ? 0u : 0xffffffffu;
 #pragma unroll
@@ -160,6 +174,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
             if (ks + RS_DEPTH == KS) pk = nbase;
 #ifndef RS_PROBE_NOLOAD
             load_next((ks + RS_DEPTH) % KS, br[ks % RS_DEPTH]);
+            load_sub((ks + RS_DEPTH) % KS, bsr[EXTRA == 2 ? ks % RS_DEPTH : 0]);
 #endif
             if (ks < KS - RS_RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
 #pragma unroll
@@ -252,7 +267,9 @@ static inline bool rs_aligned16(const void* p) { return (reinterpret_cast<uintpt
 
 // shapes / layouts the R-stationary kernel takes (channel-major on both sides is the caller's business)
 bool gemm_rs_supported(const GemmArgs& a, int n_cu) {
-    if (a.epi || a.sym || a.bsub) return false;
+    if (a.epi || a.sym) return false;
+    if (a.bsub && a.bsub_ss != 0 && a.at_ss == 0) return false;  // a workgroup keeps one matrix AND one centring vector
+    if (a.bsub && a.M > 192) return false;  // (four row tiles per wave + the centring ring spill: the LDS-tiled kernel takes these)
     if (a.M <= 128 || a.M > 256 || a.K <= 128 || a.K > 256) return false;
     if (a.n % RS_BN != 0 || a.n <= 0) return false;
     if (!rs_aligned16(a.B) || a.ldb % 4 != 0 || a.b_ss % 4 != 0) return false;
@@ -268,14 +285,16 @@ int gemm_rs_parts(long n) { return (int)(n / RS_BN); }
 template <int MT, int KS>
 static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
     const GemmArgs& a = ra.g;
-    if (a.badd || a.content)
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, true>), grid, dim3(256), 0, st, ra);
+    if (a.bsub) {
+        if constexpr (MT == 3) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2>), grid, dim3(256), 0, st, ra);
+    } else if (a.badd || a.content)
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1>), grid, dim3(256), 0, st, ra);
     else if (a.rowstat == 1)
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, false>), grid, dim3(256), 0, st, ra);
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0>), grid, dim3(256), 0, st, ra);
     else if (a.rowstat == 2)
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, false>), grid, dim3(256), 0, st, ra);
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0>), grid, dim3(256), 0, st, ra);
     else
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, false>), grid, dim3(256), 0, st, ra);
+        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0>), grid, dim3(256), 0, st, ra);
     return check_launch("gemm_rs_kernel");
 }
 

@@ -68,6 +68,7 @@ struct LoopWs {
     float *rs_a = nullptr, *rs_b = nullptr;
     int rs_parts = 0;
 
+    // Ss: segments of the ROTATED style the matcher sees (= n_seg when every segment has its own rotations)
     void layout(Bump& b, int mode, long n, long ns, int C, int n_seg, int Ss, int iters, int fused) {
         const size_t xs = (size_t)n_seg * C * n, cc = (size_t)C * C;
         rs_parts = gemm_rowstat_parts(n);
@@ -152,10 +153,10 @@ int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, 
 
 // optex.py:170  rotated = feature @ rotation  on the loop's layouts, with the per-row statistics of the result taken in the
 // GEMM's epilogue when the launch takes the hot-loop kernel (rowstat 1 = min / max, 2 = sums; *took says whether it did)
-int rotate_with_stats(const float* R, const float* x, float* y, int C, long n, int n_seg, int rowstat, float* rs_a, float* rs_b,
-                      bool* took, hipStream_t st) {
+int rotate_with_stats(const float* R, long r_ss, const float* x, float* y, int C, long n, int n_seg, int rowstat, float* rs_a,
+                      float* rs_b, bool* took, hipStream_t st) {
     GemmArgs a;
-    a.At = R; a.lda = C; a.at_ss = 0;
+    a.At = R; a.lda = C; a.at_ss = r_ss;
     a.B = x; a.ldb = n; a.b_ss = (long)C * n;
     a.O = y; a.ldo = n; a.o_ss = (long)C * n;
     a.M = C; a.K = C; a.n = n; a.n_seg = n_seg;
@@ -250,7 +251,7 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
         if (fused == 0) {
             // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (+ the row sums for the means, in the epilogue)
             bool sums = false;
-            if ((rc = rotate_with_stats(R, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st))) return rc;
+            if ((rc = rotate_with_stats(R, 0, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st))) return rc;
             // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I   (statistics of the ROTATED map, like the reference)
             if ((rc = linear_stats_parts(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes,
                                          sums ? w.rs_a : nullptr, w.rs_parts, stream)))
@@ -303,16 +304,17 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
 }  // namespace
 
 extern "C" size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters,
-                                         int fuse_rotations) {
+                                         int fuse_rotations, long r_seg_stride) {
     LoopWs w;
     Bump b(nullptr);
-    w.layout(b, mode, n, ns, C, n_seg, src_n_seg, iters, (mode < MODE_CHOL && fuse_rotations == 2) ? 0 : fuse_rotations);
+    w.layout(b, mode, n, ns, C, n_seg, r_seg_stride != 0 ? n_seg : src_n_seg, iters,
+             (mode < MODE_CHOL && fuse_rotations == 2) ? 0 : fuse_rotations);
     return b.off;
 }
 
 extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
-                             const float* R32, const float* Rt32, int iters, const float* content, float strength,
-                             int fuse_rotations, void* ws, size_t ws_bytes, void* stream) {
+                             const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content,
+                             float strength, int fuse_rotations, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !style || !R32 || !Rt32 || !ws || n <= 0 || ns <= 0 || C < 2 || n_seg <= 0 || iters < 0) {
         set_error("optex_ot_loop: bad argument (n=%ld ns=%ld C=%d n_seg=%d iters=%d)", n, ns, C, n_seg, iters);
         return OPTEX_E_ARG;
@@ -331,6 +333,14 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         return OPTEX_E_ARG;
     }
     if (!linear && fuse_rotations == 2) fuse_rotations = 0;
+    if (r_seg_stride != 0 && (linear || fuse_rotations)) {
+        set_error("optex_ot_loop: per-segment rotations (r_seg_stride != 0) are implemented for cdf / sort with fuse_rotations = 0");
+        return OPTEX_E_UNSUPPORTED;
+    }
+    if (r_seg_stride != 0 && r_seg_stride < (long)iters * C * C) {
+        set_error("optex_ot_loop: r_seg_stride %ld is smaller than one segment's rotations (%ld)", r_seg_stride, (long)iters * C * C);
+        return OPTEX_E_ARG;
+    }
     if (fuse_rotations && content && !linear) {
         set_error("optex_ot_loop: fuse_rotations needs the un-rotated pastiche between iterations for the content blend");
         return OPTEX_E_ARG;
@@ -340,12 +350,15 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         return OPTEX_E_UNSUPPORTED;
     }
     if (int rc = check_ws("optex_ot_loop", ws, ws_bytes,
-                          optex_ot_loop_ws_bytes(mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations)))
+                          optex_ot_loop_ws_bytes(mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations, r_seg_stride)))
         return rc;
     if (iters == 0) return OPTEX_OK;
     LoopWs w;
     Bump bump(ws);
-    w.layout(bump, mode, n, ns, C, n_seg, src_n_seg, iters, fuse_rotations);
+    // With its own rotations every segment sees its own rotated copy of the style: the matchers then run one source
+    // segment per target segment (nothing on the style side is shared any more, optex.py:168-171 run per image).
+    const int rs_seg = r_seg_stride != 0 ? n_seg : src_n_seg;
+    w.layout(bump, mode, n, ns, C, n_seg, rs_seg, iters, fuse_rotations);
     if (linear)
         return linear_loop(mode, x, n, n_seg, style, ns, src_n_seg, C, R32, Rt32, iters, content, strength, fuse_rotations, w, stream);
 
@@ -397,20 +410,21 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (cdf: + per-channel min / max in the epilogue, which
         // saves histmatch.py:52-53 its own pass over the rotated map)
         bool mm = false;
-        if ((rc = rotate_with_stats(R, x, w.y, C, n, n_seg, mode == MODE_CDF ? 1 : 0, w.rs_a, w.rs_b, &mm, st))) return rc;
-        // optex.py:171  rotated_style = style_feature @ rotation
-        if ((rc = optex_gemm_tn(R, C, 0, style, ns, ss, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C, C,
-                                ns, src_n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+        if ((rc = rotate_with_stats(R, r_seg_stride, x, w.y, C, n, n_seg, mode == MODE_CDF ? 1 : 0, w.rs_a, w.rs_b, &mm, st)))
+            return rc;
+        // optex.py:171  rotated_style = style_feature @ rotation   (one copy per rotation set)
+        if ((rc = optex_gemm_tn(R, C, r_seg_stride, style, ns, src_n_seg > 1 ? ss : 0, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss,
+                                OPTEX_CHANNEL_MAJOR, C, C, ns, rs_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
             return rc;
         // optex.py:173  hist_match(rotated_pastiche, rotated_style), in place
         if (mode == MODE_CDF)
-            rc = cdf_match_parts_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr,
+            rc = cdf_match_parts_impl(w.y, n, xs, n, w.ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr,
                                       mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, st);
         else
-            rc = sort_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, w.y, n, xs, w.mode_ws, st);
+            rc = sort_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, st);
         if (rc) return rc;
         // optex.py:175 + 115-117  pastiche = matched @ rotation.T ; content blend
-        if ((rc = optex_gemm_tn(Rt, C, 0, w.y, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
+        if ((rc = optex_gemm_tn(Rt, C, r_seg_stride, w.y, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
                                 nullptr, 0, nullptr, 0, content, strength, stream)))
             return rc;
     }

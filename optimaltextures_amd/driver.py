@@ -111,6 +111,16 @@ def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content:
     s, c, n = x.shape
     if iters <= 0:
         return x
+    if isinstance(rng, (list, tuple)):
+        # one numpy stream per texture: every segment draws its own rotations, like the reference run once per image
+        if pooled or len(rng) != s:
+            raise ValueError(f"per-texture rotation streams need independent textures and one stream per texture (got {len(rng)} for {s})")
+        if hist_mode not in ("cdf", "sort"):
+            raise NotImplementedError("per-texture rotation sequences are implemented for hist_mode cdf / sort")
+        R32, Rt32 = rotation.rotations_per_segment(c, iters, x.device, rng)
+        if content is not None and content.shape[0] != s:
+            content = content.expand(s, c, n).contiguous()
+        return ops.ot_loop(hist_mode, x, style, R32, Rt32, content=content, strength=strength)
     R32, Rt32 = rotation.rotations(c, iters, x.device, rng=rng)
     if content is not None and content.shape[0] != s:
         content = content.expand(s, c, n).contiguous()
@@ -188,7 +198,10 @@ class OptimalTexture(torch.nn.Module):
         # layers keeps by default.  index_by_position=True reproduces a reference whose list holds only `layers`.
         self.index_by_position = index_by_position
         self.style_sync = None  # multi-GPU hook: callable(list of tensors or None) -> list of tensors (dist.py)
-        self.rng = None         # numpy RandomState for the rotations (None = numpy's global state, like the reference)
+        # numpy RandomState for the rotations (None = numpy's global state, like the reference: ONE sequence shared by the
+        # whole batch, optex.py:168-170), or a list of one RandomState per texture (independent=True, cdf / sort): every
+        # texture then draws its own rotations — the batch equals B separate runs of the reference, seed for seed
+        self.rng = None
 
     # -- optex.py:45-79, channel-major
     def _needs_resize(self, hw, size: int) -> bool:

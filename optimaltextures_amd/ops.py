@@ -206,22 +206,26 @@ def rotations_from_normals(normals, N, count, device, want64=False):
 
 def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False):
     """optex.py:112-117, all iterations enqueued by one C call, for every hist_mode; x [S, C, n] (independent segments) is
-    updated IN PLACE.  fuse_rotations = True / 1 (labelled fast paths, fp32 round-off differences only): cdf / sort evaluate
-    (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (needs content=None); the linear modes run the whole step as one
-    affine map in un-rotated space."""
+    updated IN PLACE.  R32 / Rt32: [iters, C, C] shared by all segments (the reference shares R across its batch), or
+    [S, iters, C, C]: one rotation set per segment (cdf / sort).  fuse_rotations = True / 1 (labelled fast paths, fp32
+    round-off differences only): cdf / sort evaluate (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (needs content=None);
+    the linear modes run the whole step as one affine map in un-rotated space."""
     lib = _lib.lib()
     S, C, n = x.shape
     Ss, Cs, ns = style.shape
     assert Cs == C and x.is_contiguous() and style.is_contiguous()
-    iters = R32.shape[0]
-    assert R32.shape == (iters, C, C) and Rt32.shape == (iters, C, C) and R32.is_contiguous() and Rt32.is_contiguous()
+    per_seg = R32.dim() == 4
+    iters = R32.shape[1] if per_seg else R32.shape[0]
+    shape = (S, iters, C, C) if per_seg else (iters, C, C)
+    assert R32.shape == shape and Rt32.shape == shape and R32.is_contiguous() and Rt32.is_contiguous()
+    r_ss = iters * C * C if per_seg else 0
     if content is not None:
         assert content.shape == x.shape and content.is_contiguous()
     m = LOOP_MODES[mode]
     # 0 = default, 1 / True = labelled fast path, 2 = linear modes with the apply and the rotation back as separate GEMMs
     fuse = int(fuse_rotations) if (content is None or m >= 2) else (0 if int(fuse_rotations) == 1 else int(fuse_rotations))
-    ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse), x.device)
-    check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), iters,
+    ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse, r_ss), x.device)
+    check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), r_ss, iters,
                             ptr(content), ctypes.c_float(strength), fuse, ptr(ws), ws.numel(), stream_ptr()))
     return x
 

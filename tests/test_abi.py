@@ -23,14 +23,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/optex.h but not exported by liboptex_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes and header disagree"
-    assert lib.optex_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.optex_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_size_helpers_need_no_gpu():
     lib = _lib.load()
     assert lib.optex_rotation_normals(256) == 256 * 257 // 2 - 1 == 32895
     assert lib.optex_cdf_ws_bytes(256, 4) > 4 * 256 * (4 * 4 + 2 * 256 * 4 + 3 * 256 * 4) - 1
-    assert lib.optex_ot_loop_ws_bytes(0, 16384, 12288, 256, 2, 1, 13, 0) >= (2 * 16384 + 12288) * 256 * 4
+    assert lib.optex_ot_loop_ws_bytes(0, 16384, 12288, 256, 2, 1, 13, 0, 0) >= (2 * 16384 + 12288) * 256 * 4
 
 
 def test_argument_errors_are_reported_without_launching():
@@ -68,11 +68,11 @@ def test_undersized_scratch_is_refused_before_any_launch():
     assert b"optex_linear_stats" in lib.optex_last_error()
     assert lib.optex_rotations_from_normals(p, 4, 2, None, p, p, p, lib.optex_rotation_ws_bytes(4, 2) - 1, None) == -1
     for mode in (0, 1):
-        need = lib.optex_ot_loop_ws_bytes(mode, n, ns, C, S, 1, 3, 0)
-        assert lib.optex_ot_loop(mode, p, n, S, p, ns, 1, C, p, p, 3, None, 0.0, 0, p, need - 1, None) == -1
+        need = lib.optex_ot_loop_ws_bytes(mode, n, ns, C, S, 1, 3, 0, 0)
+        assert lib.optex_ot_loop(mode, p, n, S, p, ns, 1, C, p, p, 0, 3, None, 0.0, 0, p, need - 1, None) == -1
         assert b"optex_ot_loop" in lib.optex_last_error()
     # the sort-mode loop scratch covers pastiche columns longer than one LDS (it was sized with nt = 0)
-    big = lib.optex_ot_loop_ws_bytes(1, 65536, 49152, 64, 1, 1, 4, 0)
+    big = lib.optex_ot_loop_ws_bytes(1, 65536, 49152, 64, 1, 1, 4, 0, 0)
     fixed = 4 * 64 * (65536 + 49152)
     assert big - fixed >= lib.optex_sort_match_ws_bytes(65536, 49152, 64, 1, 1)
 

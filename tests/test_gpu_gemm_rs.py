@@ -87,3 +87,27 @@ def test_rs_gemm_nonfinite_rows_beyond_k_do_not_leak(dev):
     ops.gemm_tn(cu(At, dev), cu(x, dev), out, M, K, n, S, lda=M, ldb=n, b_ss=K * n, ldo=n, o_ss=M * n)
     got = out.cpu().numpy()
     assert np.isfinite(got[0]).all() and biteq(got[0], orc.gemm_tn(At, x[0]))
+
+
+@pytest.mark.parametrize("M,K", [(181, 181), (165, 165), (181, 256), (192, 192)])
+def test_rs_gemm_centred_operand_bit_exact(dev, M, K):
+    """the apply step of the linear modes at PCA ranks (histmatch.py:27/34/42,44: T @ (hist_t - mu_t) + mu_s): per-segment
+    operators, per-segment centring vector and bias, content blend — one subtraction per operand element, one rounding"""
+    from optimaltextures_amd import ops
+    S, n = 8, 4096
+    rng = np.random.default_rng(M * 3 + K)
+    x = rng.standard_normal((S, K, n)).astype(np.float32)
+    At = (rng.standard_normal((S, K, M)) / 8).astype(np.float32)
+    bsub = rng.standard_normal((S, K)).astype(np.float32)
+    badd = rng.standard_normal((S, M)).astype(np.float32)
+    content = rng.standard_normal((S, M, n)).astype(np.float32)
+    out = torch.empty((S, M, n), dtype=torch.float32, device=dev)
+    ops.gemm_tn(cu(At, dev), cu(x, dev), out, M, K, n, S, lda=M, at_ss=K * M, ldb=n, b_ss=K * n, ldo=n, o_ss=M * n,
+                bsub=cu(bsub, dev), bsub_ss=K, badd=cu(badd, dev), badd_ss=M, content=cu(content, dev), strength=0.05)
+    got = out.cpu().numpy()
+    for s_ in (0, 4, 7):
+        want = orc.content_blend(orc.gemm_tn(At[s_], x[s_], bsub[s_], badd[s_]), content[s_], 0.05)
+        assert biteq(got[s_], want), f"segment {s_}"
+    out2 = torch.empty_like(out)  # centring only, one shared vector and one shared matrix
+    ops.gemm_tn(cu(At[1], dev), cu(x, dev), out2, M, K, n, S, lda=M, ldb=n, b_ss=K * n, ldo=n, o_ss=M * n, bsub=cu(bsub[2], dev))
+    assert biteq(out2.cpu().numpy()[5], orc.gemm_tn(At[1], x[5], bsub[2], None))

@@ -298,6 +298,8 @@ def test_sort_radix_sweep_every_instantiation(dev, nt, ns):
     """the LSD radix kernel behind the ranking kernel (csrc/sort.hip) at each of its keys-per-thread instantiations: every
     column carries a NaN / an infinity, so the fast path flags it and the sweep sorts it (below RK_MIN_N = 512 keys the
     radix kernel is the only path).  Match and emit, against the oracle, NaNs included (IEEE totalOrder)."""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
     rng = np.random.default_rng(nt * 3 + ns)
     names, t = _sort_edge_columns(nt, rng)
     t = t.copy()
@@ -702,6 +704,44 @@ def test_ot_loop_at_the_bench_shape_vs_oracle(dev, mode, C, blend):
             assert biteq(got[s], w), f"{mode} C={C} segment {s}: {np.count_nonzero(got[s] != w)} elements differ"
         else:
             assert maxrel(got[s], w) <= 2 * LIN_TOL, f"{mode} C={C} segment {s}: {maxrel(got[s], w):.2e}"
+
+
+@pytest.mark.parametrize("mode,S,C,n,ns,blend", [("cdf", 3, 32, 1024, 768, False), ("sort", 2, 16, 576, 560, True),
+                                                  ("cdf", 8, 256, 4096, 3072, False), ("cdf", 4, 181, 4096, 3072, True)])
+def test_per_texture_rotation_streams_equal_separate_runs(dev, mode, S, C, n, ns, blend):
+    """un-shared rotations (optex.py:168: the reference run once per image draws its own R every
+    iteration): texture i of a batch driven by one numpy stream per texture equals the B = 1 run with stream i, bit for
+    bit, and that run equals the oracle chain.  (A shared-rotation batch differs: the control.)"""
+    from optimaltextures_amd import driver
+    rng = np.random.default_rng(S * C + n)
+    x = relu_feat(rng, S, C, n, scale=2.0, shift=0.3)
+    sty = relu_feat(rng, 1, C, ns, scale=1.5, shift=0.5)
+    content = relu_feat(rng, S, C, n, scale=2.0) if blend else None
+    iters, seeds = 3, [1000 + 7 * i for i in range(S)]
+    xd = cu(x, dev)
+    driver.ot_iterations(xd, cu(sty, dev), mode, iters, content=cu(content, dev) if blend else None,
+                         strength=0.05 if blend else 0.0, rng=[np.random.RandomState(sd) for sd in seeds])
+    batch = xd.cpu().numpy()
+    for i in range(S):
+        xi = cu(x[i:i + 1], dev)
+        driver.ot_iterations(xi, cu(sty, dev), mode, iters, content=cu(content[i:i + 1], dev) if blend else None,
+                             strength=0.05 if blend else 0.0, rng=np.random.RandomState(seeds[i]))
+        assert biteq(batch[i], xi.cpu().numpy()[0]), f"texture {i}"
+    # the oracle chain on one texture, with the rotations its stream yields (device Householder chain, <= 1 ulp of scipy's)
+    from optimaltextures_amd import rotation
+    i = S - 1
+    Rs = rotation.rotations(C, iters, dev, rng=np.random.RandomState(seeds[i]))[0].cpu().numpy()
+    w = x[i]
+    for R in Rs:
+        rp, rs = orc.rotate_cm(w, R), orc.rotate_cm(sty[0], R)
+        w = orc.unrotate_cm(orc.cdf_match(rp, rs) if mode == "cdf" else orc.sort_match(rp, rs), R)
+        if blend:
+            w = orc.content_blend(w, content[i], 0.05)
+    assert biteq(batch[i], w)
+    shared = cu(x, dev)
+    driver.ot_iterations(shared, cu(sty, dev), mode, iters, content=cu(content, dev) if blend else None,
+                         strength=0.05 if blend else 0.0, rng=np.random.RandomState(seeds[0]))
+    assert biteq(shared.cpu().numpy()[0], batch[0]) and not biteq(shared.cpu().numpy()[1], batch[1])
 
 
 # ================================================================================================ full-size (BASELINE) properties
