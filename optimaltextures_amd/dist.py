@@ -73,6 +73,39 @@ class StyleSync:
     def header_len(n_tensors: int, n_ints: int) -> int:
         return 3 + n_tensors * (1 + MAX_DIMS) + n_ints
 
+    def broadcast_known(self, tensors: Optional[List[torch.Tensor]], shapes: List[Tuple[int, ...]]):
+        """The exchange when every rank can compute every SHAPE in advance (no PCA: the rank k is the only data-dependent
+        size): no header, no host synchronisation at all — ONE asynchronous payload broadcast; the receiving ranks keep
+        enqueueing kernels behind it.  source: list of fp32 tensors of exactly these shapes -> everyone: the tensors."""
+        if self.world == 1 and not self.always:
+            return list(tensors)
+        numels = [int(torch.Size(sh).numel()) for sh in shapes]
+        total = sum(_padded(k) for k in numels)
+        flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        if self.is_source:
+            bad = tensors is None or len(tensors) != len(shapes) or any(tuple(t.shape) != tuple(sh) or t.dtype != torch.float32
+                                                                       for t, sh in zip(tensors or [], shapes))
+            if bad:
+                # the payload still goes out (nobody is left waiting in a collective); a NaN in the first word marks it
+                flat.fill_(float("nan"))
+            else:
+                off = 0
+                for t, k in zip(tensors, numels):
+                    flat[off:off + k].copy_(t.reshape(-1))
+                    off += _padded(k)
+        work = dist.broadcast(flat, self.src, group=self.group, async_op=True) if total else None
+        self.messages += 1 if total else 0
+        self.bytes_moved += total * 4
+        out, off = [], 0
+        for sh, k in zip(shapes, numels):
+            out.append(flat[off:off + k].view(tuple(sh)))
+            off += _padded(k)
+        if work is not None:
+            work.wait()  # RCCL: the current stream waits for the communicator's stream, the host does not block
+        if self.is_source and bad:
+            raise ValueError("StyleSync.broadcast_known: the source rank's tensors do not have the announced shapes")
+        return out
+
     def broadcast_packed(self, tensors: Optional[List[torch.Tensor]], ints: Optional[List[int]] = None,
                          counts: Optional[Tuple[int, int]] = None):
         """source: (list of fp32 tensors, list of ints) -> everyone: (list of tensors, list of ints).

@@ -270,20 +270,43 @@ class OptimalTexture(torch.nn.Module):
     def prefetch_style_sides(self, pastiche_hw, styles: List[Tensor], content: Optional[Tensor]):
         """The style side of EVERY pass, before the first one starts.  It depends on the pastiche only through its
         size, which is known in advance (each pass leaves the pastiche at its content size).  With a style_sync hook the
-        source rank encodes them all and ONE packed broadcast carries them: the receiving ranks pay a single host
-        synchronisation (the PCA shapes are data dependent) at the start of a forward call, before their kernel queue
-        fills, instead of one per (pass, layer) in the middle of it."""
-        hw, sides = (int(pastiche_hw[0]), int(pastiche_hw[1])), []
+        source rank encodes them all and ONE exchange carries them.
+        Without PCA every shape is computable on every rank (Encoder.out_shape of the — globally known — style image size):
+        the exchange is a single asynchronous payload broadcast with NO host synchronisation on any rank
+        (StyleSync.broadcast_known); `styles` must then have the true shapes on every rank, their content matters on the
+        source rank only.  With PCA the rank k is data dependent: one int64 header (the one host synchronisation of a
+        forward call on the receiving ranks) precedes the payload (StyleSync.broadcast_packed)."""
+        hw, plan = (int(pastiche_hw[0]), int(pastiche_hw[1])), []
         need = self.style_sync is None or self.style_sync.is_source
         for p in range(self.passes):
             size = self.sizes[p]
             resized = self._needs_resize(hw, size)
-            if need:
-                sides.append((resized,) + self._compute_style_side(self._style_tensors(styles, size, resized)))
+            plan.append((size, resized))
             if resized:
                 hw = (get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True) if content is not None
                       else (size, size))
-        return self._sync_style_sides(sides if need else None, self.passes)
+        sides = [(resized,) + self._compute_style_side(self._style_tensors(styles, size, resized)) for size, resized in plan] if need else None
+        if self.style_sync is None or self.use_pca:
+            return self._sync_style_sides(sides, self.passes)
+        # shapes from the layer lists alone
+        shapes, hws = [], []
+        for size, resized in plan:
+            per_pass = []
+            for encoder in self.encoders:
+                dims = [get_size(size, self.style_scale, st.shape[2], st.shape[3]) if resized else (int(st.shape[2]), int(st.shape[3]))
+                        for st in styles]
+                c, h, w = encoder.out_shape(*dims[0])
+                assert all(encoder.out_shape(*d) == (c, h, w) for d in dims), "style images must have the same shape"
+                shapes.append((len(styles), c, h * w))
+                per_pass.append((h, w))
+            hws.append(per_pass)
+        flat = [f for side in sides for f in side[1]] if need else None
+        got = self.style_sync.broadcast_known(flat, shapes)
+        n_enc, out = len(self.encoders), []
+        for p, (size, resized) in enumerate(plan):
+            feats = got[p * n_enc:(p + 1) * n_enc]
+            out.append((resized, feats, [torch.empty((0, 0), device=f.device) for f in feats], hws[p]))
+        return out
 
     def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int,
                       style_side=None):

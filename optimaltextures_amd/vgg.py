@@ -152,6 +152,21 @@ class Encoder(_Codec):
     def __init__(self, depth: int, models_dir=None, allow_synthetic=False):
         super().__init__(depth, encoder_layers(depth), models_dir, seed=100, allow_synthetic=allow_synthetic)
 
+    def out_shape(self, h: int, w: int):
+        """(C, H', W') of features() for an H x W image, from the layer list alone (no convolution is run): what a rank
+        that only RECEIVES style features needs in order to know their shapes in advance (dist.StyleSync)"""
+        c = 3
+        for m in self.model:
+            if isinstance(m, nn.Conv2d):
+                c = m.out_channels
+                h, w = h - (m.kernel_size[0] - 1), w - (m.kernel_size[1] - 1)
+            elif isinstance(m, nn.ReflectionPad2d):
+                l, r, t, b = m.padding
+                h, w = h + t + b, w + l + r
+            elif isinstance(m, nn.MaxPool2d):
+                h, w = (h + 1) // 2, (w + 1) // 2  # kernel 2, stride 2, ceil_mode=True (vgg.py:26)
+        return c, h, w
+
     def features(self, x):
         """NCHW image -> NCHW feature (channel-major per image: the layout every OT kernel wants)"""
         if x.is_cuda and not torch.is_grad_enabled():

@@ -225,10 +225,11 @@ def _bench_step_job(rank, world, device):
 def test_bench_step_with_style_sync_gloo_world2():
     """Both ranks run the whole forward() with the packed style broadcast; rank 1 (blank local style) must produce exactly
     what a single process computes for rank 1's seeds with the real style: the broadcast delivered rank 0's style side for
-    every pass, and nothing else crossed ranks.  One exchange per forward call = 2 messages."""
+    every pass, and nothing else crossed ranks.  Without PCA every shape is known in advance: one exchange per forward
+    call = ONE message (the payload), no header and no host synchronisation."""
     res = run_world(_bench_step_job, 2)
     (out0, (msgs0, bytes0)), (out1, (msgs1, bytes1)) = res[0], res[1]
-    assert msgs0 == msgs1 == 2 and bytes0 == bytes1 > 0
+    assert msgs0 == msgs1 == 1 and bytes0 == bytes1 > 0
     assert out0.shape == out1.shape == (2, 3, 288, 288) and np.isfinite(out0).all() and np.isfinite(out1).all()
     assert not np.array_equal(out0, out1)                      # different seeds per rank: different textures
 
@@ -314,3 +315,29 @@ def test_bench_refuses_a_world_that_differs_from_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry_run"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def _known_shapes_job(rank, world, device):
+    """StyleSync.broadcast_known: shapes agreed in advance, one message; a source whose tensors do not fit raises — after
+    the collective, so the receiver is not left waiting (it gets the marked payload and carries on to ITS next collective)"""
+    sync = otdist.StyleSync(device)
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1, 8, 24), (2, 5), (0, 0)]
+    payload = [torch.rand(sh, generator=g) for sh in shapes] if sync.is_source else None
+    got = sync.broadcast_known(payload, shapes)
+    raised = False
+    try:
+        sync.broadcast_known([torch.zeros(3)] if sync.is_source else None, [(4,)])
+    except ValueError:
+        raised = True
+    again = sync.broadcast_known([torch.full((4,), 1.5)] if sync.is_source else None, [(4,)])
+    return [t.numpy().copy() for t in got], sync.messages, raised, again[0].tolist()
+
+
+def test_style_sync_known_shapes_single_message_gloo_world2():
+    res = run_world(_known_shapes_job, 2)
+    (a, ma, ra, aa), (b, mb, rb, ab) = res[0], res[1]
+    assert ma == mb == 3 and ra and not rb and aa == ab == [1.5] * 4
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)
+    assert a[2].shape == (0, 0)

@@ -193,3 +193,16 @@ def test_image_io_round_trip_and_names(tmp_path):
     assert tuple(back.shape) == (1, 3, 32, 32)
     raw = torch.from_numpy(__import__("numpy").array(Image.open(paths[1]).convert("RGB"))).permute(2, 0, 1) / 255.0
     assert float((raw - img[1].clamp(0, 1)).abs().max()) <= 0.5 / 255 + 1e-6
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5])
+def test_encoder_out_shape_matches_the_convolutions(depth):
+    """Encoder.out_shape (what a rank that only receives style features uses to know their shapes, dist.StyleSync) against
+    the real layer stack, odd sizes included (ceil_mode pooling, vgg.py:26)"""
+    import torch
+    from optimaltextures_amd.vgg import Encoder
+    enc = Encoder(depth).eval()
+    for h, w in [(32, 32), (37, 50), (96, 65), (33, 129)]:
+        with torch.inference_mode():
+            f = enc.features(torch.rand(1, 3, h, w))
+        assert tuple(f.shape[1:]) == enc.out_shape(h, w), (depth, h, w)
