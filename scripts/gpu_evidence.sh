@@ -1,0 +1,51 @@
+#!/bin/bash
+# Every measurement kept under profiles/ for one commit, in one GPU-box session:
+#   gpurun --timeout 2400 -- 'bash scripts/gpu_evidence.sh <tag> <commit>'
+# default bench line; rocprofv3 kernel-trace summaries of the bench (cdf, sort, chol); PMC HBM traffic (FETCH_SIZE / WRITE_SIZE,
+# separate passes, kernel-trace only) of the bench in cdf and sort mode; SQ / MFMA counters of the hot GEMMs (both row-statistics
+# variants run inside the cdf loop) and of the sort match kernel.  Everything lands under gpurun_out/<tag>/ with the commit
+# hash inside each file; copy what is to be judged into profiles/.
+TAG=${1:-evidence}
+COMMIT=${2:-unknown}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+STAMP="round 3, commit $COMMIT, one MI355X"
+( timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "rc=$?" >> $OUT/bench_default.err )
+tail -c 400 $OUT/bench_default.json; echo
+for MODE in cdf sort chol; do
+  ( timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$MODE -o prof -- python bench.py --hist_mode $MODE --steps 2 --warmup 1 --no_cpu_baseline --other_modes "" > $OUT/prof_$MODE.log 2>&1; echo "rc=$?" >> $OUT/prof_$MODE.log )
+  python scripts/summarize_rocprof.py $OUT/prof_$MODE/prof_kernel_trace.csv --warmup 1 --title "bench.py --hist_mode $MODE, 64 textures per step ($STAMP)" --out $OUT/bench_b64_${MODE}_kernel_summary.md > /dev/null 2>&1
+  rm -rf $OUT/prof_$MODE
+done
+head -24 $OUT/bench_b64_cdf_kernel_summary.md
+for MODE in cdf sort; do
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $CTR -f csv -d $OUT/${MODE}_$CTR -o pmc -- python bench.py --hist_mode $MODE --steps 1 --warmup 1 --no_cpu_baseline --other_modes "" --no_kernel_timing > $OUT/${MODE}_$CTR.log 2>&1
+  done
+  python scripts/summarize_pmc.py $OUT/${MODE}_FETCH_SIZE/pmc_counter_collection.csv $OUT/${MODE}_WRITE_SIZE/pmc_counter_collection.csv --out $OUT/pmc_traffic_$MODE.json --measured "$STAMP" --command "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --hist_mode $MODE --steps 1 --warmup 1 --no_cpu_baseline --other_modes '' --no_kernel_timing" > $OUT/pmc_traffic_$MODE.log 2>&1
+  rm -rf $OUT/${MODE}_FETCH_SIZE $OUT/${MODE}_WRITE_SIZE
+done
+python - <<PY
+import json
+for m in ("cdf", "sort"):
+    try:
+        d = json.load(open("$OUT/pmc_traffic_%s.json" % m))
+        print(m, {k: round(v["hbm_bytes"] / 1e6, 1) for k, v in d["kernels"].items()})
+    except Exception as e:
+        print(m, "failed", e)
+PY
+# hot GEMMs inside the cdf loop: rowstat variant (forward rotation) and plain variant (inverse rotation), at [64, 256, 16384]
+MB="python scripts/microbench.py --only loop --S 64 --reps 3"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU -f csv -d $OUT/gemm_sq -o pmc -- $MB > $OUT/gemm_sq.log 2>&1
+python scripts/summarize_sq.py $OUT/gemm_sq/pmc_counter_collection.csv --match gemm --skip 2 --title "rotation GEMMs inside optex_ot_loop(cdf), [64, 256, 16384] ($STAMP)" --command "rocprofv3 --kernel-trace --pmc <SQ counters> -- $MB" --out $OUT/gemm_mfma_counters.md > /dev/null 2>&1
+rm -rf $OUT/gemm_sq
+grep -E "^## |MFMA util|effective" $OUT/gemm_mfma_counters.md
+# sort match kernel: instruction mix, wait states, LDS
+MB="python scripts/microbench.py --only sortmatch --S 64 --reps 6"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -f csv -d $OUT/sort_sq1 -o pmc -- $MB > $OUT/sort_sq1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE -f csv -d $OUT/sort_sq2 -o pmc -- $MB > $OUT/sort_sq2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN -f csv -d $OUT/sort_sq3 -o pmc -- $MB > $OUT/sort_sq3.log 2>&1
+python scripts/summarize_sq.py $OUT/sort_sq1/pmc_counter_collection.csv $OUT/sort_sq2/pmc_counter_collection.csv $OUT/sort_sq3/pmc_counter_collection.csv --match rank_match4 --skip 3 --elements $((64*256*16384)) --title "rank_match4_kernel ([64, 256, 16384] against a [1, 256, 12288] style): instruction mix and wait states ($STAMP)" --command "rocprofv3 --kernel-trace --pmc <counters> -- $MB" --out $OUT/sort_match4_sq_counters.md > /dev/null 2>&1
+rm -rf $OUT/sort_sq1 $OUT/sort_sq2 $OUT/sort_sq3
+tail -n 14 $OUT/sort_match4_sq_counters.md

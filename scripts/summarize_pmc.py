@@ -16,10 +16,10 @@ import csv
 import json
 import re
 
-CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"),
+CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("gemm_rs_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"),
             ("col_hist_kernel", "col_hist"), ("col_minmax_kernel", "col_minmax"), ("cdf_lut_kernel", "cdf_lut"),
             ("glue_kernel", "vgg_glue"), ("glue_nhwc_kernel", "vgg_glue"), ("glue_transpose", "vgg_glue"),
-            ("rank_match_kernel", "sort_match"), ("rank_match3_kernel", "sort_match"), ("rank_match4_kernel", "sort_match"), ("rank_columns_kernel", "sort_rank"),
+            ("rank_match4_kernel", "sort_rank4"),
             ("gram128_kernel", "gram"), ("minmax_from_parts_kernel", "col_minmax"), ("mean_from_parts_kernel", "col_mean"),
             ("chol_inv_kernel", "chol_inv"), ("ns_init_kernel", "ns_init"), ("cov_finalize_kernel", "cov_finalize"), ("sort_columns_kernel", "sort_radix"), ("gram_kernel", "gram"),
             ("col_mean_kernel", "col_mean"), ("householder_apply", "householder")]
@@ -28,9 +28,9 @@ CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("cd
 def classify(name):
     for key, cls in CLASS_OF:
         if key in name:
-            if cls == "sort_rank":
-                m = re.search(r"rank_columns_kernel<\d+, (\d)>", name)
-                return "sort_match" if m and m.group(1) == "1" else "sort_columns"
+            if cls == "sort_rank4":  # rank_match4_kernel<ITEMS, VEC, NT, FULL, MODE>: MODE 1 = match, 0 = emit (sort_columns)
+                m = re.search(r"rank_match4_kernel<[^>]*, (\d)>", name)
+                return "sort_columns" if m and m.group(1) == "0" else "sort_match"
             return cls
     return None
 
