@@ -317,6 +317,17 @@ def test_sort_radix_sweep_every_instantiation(dev, nt, ns):
     assert np.array_equal(idx.cpu().numpy()[0].astype(np.int64), wi.astype(np.int64))
 
 
+def test_sort_stress_slice(dev):
+    """200 cases of scripts/sort_stress.py (the round-2 stress ran 5300 outside the suite): column lengths around every
+    workgroup-shape boundary of csrc/sort_rank4.hip, source lengths below / equal / above, mixed edge distributions,
+    unaligned views — optex_sort_match and optex_sort_columns against the oracle, 0 mismatches"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sort_stress.py"), "200", "31"], capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0 and "200 cases, 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _ulp_clusters(n, rng):
     base = rng.standard_normal((n + 2) // 3).astype(np.float32)
     c = np.stack([base, np.nextafter(base, np.float32(np.inf)), np.nextafter(base, np.float32(-np.inf))], 1).reshape(-1)[:n]
