@@ -52,7 +52,7 @@ def make_texturizer(hist_mode, device, fuse_rotations=False, no_pca=True, indepe
 
 def pmc_traffic():
     """HBM-side bytes per launch per kernel class from the committed rocprofv3 PMC passes of this same command
-    (profiles/pmc_traffic.json, produced by scripts/gpu_pmc_traffic.sh + scripts/summarize_pmc.py).  The counters cannot
+    (profiles/pmc_traffic.json, produced by scripts/gpu_evidence.sh + scripts/summarize_pmc.py + scripts/collect_profiles.py).  The counters cannot
     be read from inside the process, so the numbers are those of an EARLIER profiled run of the same workload, not of
     this run: `traffic_source` in the JSON line names the file and what it was measured on."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -210,6 +210,7 @@ def main():
                     help="one extra step each (N = 1 only); 'fused' = the labelled re-association fast paths, "
                          "'refdefaults' = chol + PCA + pooled batch (the reference's own defaults), 'assets' = the headline "
                          "configuration on the reference's real relu3_1 weights and style/graffiti.jpg (assets/)")
+    ap.add_argument("--pca", action="store_true", help="PCA on (the reference's default flags; NOT the headline configuration, which is C=256 / no_pca): profiling the PCA path")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
     ap.add_argument("--no_miopen_find", action="store_true", help="torch.backends.cudnn.benchmark = False: MIOpen picks the convolution kernels from its heuristics / find-db instead of timing every solver in the warm-up step")
@@ -243,7 +244,7 @@ def main():
 
     B = args.batch
     style = synthetic_style(device)
-    tex = make_texturizer(args.hist_mode, device)
+    tex = make_texturizer(args.hist_mode, device, no_pca=not args.pca)
     if world > 1:
         tex.style_sync = otdist.StyleSync(device)  # rank 0 encodes the style, ONE packed RCCL broadcast per forward call
     # Seeding rule of sharded jobs (optimaltextures_amd/dist.py): textures are numbered globally; the B textures of one step of
@@ -290,7 +291,7 @@ def main():
         "metric": "512^2 textures/sec (relu3_1, default iters)", "value": round(value, 3), "unit": "textures/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{B} independent 512^2 textures per GPU per step, VGG relu3_1 only, C=256 (no_pca), "
+        "config": {"workload": f"{B} independent 512^2 textures per GPU per step, VGG relu3_1 only, {'C=k (PCA on)' if args.pca else 'C=256 (no_pca)'}, "
                                f"5 passes 256..512, 52 OT iterations (default iters=500), hist_mode={args.hist_mode}, "
                                "style 736x512 synthetic, random-init VGG weights",
                    "textures_per_gpu_per_step": B, "hist_mode": args.hist_mode, "parallelism": f"textures x{world}",

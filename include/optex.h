@@ -161,7 +161,7 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
  *   reference shares one R across its batch, optex.py:168-170), or one set per segment, R32 + s * r_seg_stride (ABI 5:
  *   r_seg_stride >= iters * C * C elements; the reference run once per image draws its own rotations every time).  With
  *   per-segment rotations nothing on the style side is shared either: every segment is matched to its own rotated copy
- *   of the style.  Implemented for modes 0 / 1 with fuse_rotations = 0 (OPTEX_E_UNSUPPORTED otherwise).
+ *   of the style (linear modes: to the style statistics rotated by its own matrices).  cdf / sort: fuse_rotations = 0 only.
  * mode: 0 = cdf, 1 = sort, 2 = chol, 3 = pca, 4 = sym (histmatch.py:5 `mode`; eps = 1 as every caller leaves it).
  *   The linear modes (2-4) take the style's mean and covariance ONCE per call and rotate them as C x C matrices
  *   (cov(S R) = R^T cov(S) R — the style-feature statistics the multi-GPU path broadcasts); the pastiche side is the

@@ -37,11 +37,13 @@ int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, 
     return gemm_tn_launch(a, OPTEX_CHANNEL_MAJOR, OPTEX_CHANNEL_MAJOR, st);
 }
 
-// out[b][m] = sum_k R[b / per][k][m] * mu[(b % per)][k]   — the rotated style mean  mu_s @ R  (optex.py:171 + histmatch.py:20)
-__global__ void rot_mean_kernel(const float* __restrict__ R, const float* __restrict__ mu, int C, int per, float* __restrict__ out) {
-    const int b = blockIdx.x, it = b / per, s = b % per;
-    const float* r = R + (size_t)it * C * C;
-    const float* m = mu + (size_t)s * C;
+// out[b][m] = sum_k R_g[it][k][m] * mu[s(g)][k]  for b = it * per + g — the rotated style mean  mu_s @ R  (optex.py:171 +
+// histmatch.py:20); set g's rotations start at R + g * r_ss (r_ss = 0: shared), its style segment is g (mu_per_set) or 0
+__global__ void rot_mean_kernel(const float* __restrict__ R, long r_ss, const float* __restrict__ mu, int mu_per_set, int C, int per,
+                                float* __restrict__ out) {
+    const int b = blockIdx.x, it = b / per, g = b % per;
+    const float* r = R + (size_t)g * r_ss + (size_t)it * C * C;
+    const float* m = mu + (size_t)(mu_per_set ? g : 0) * C;
     for (int j = threadIdx.x; j < C; j += blockDim.x) {
         float acc = 0.f;
         for (int k = 0; k < C; k++) acc = __builtin_fmaf(r[(size_t)k * C + j], m[k], acc);

@@ -20,7 +20,8 @@ int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, 
                int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st, bool sym);
 int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O, int C, int batch, float alpha,
                   const float* alpha_seg, float diag, hipStream_t st);
-__global__ void rot_mean_kernel(const float* __restrict__ R, const float* __restrict__ mu, int C, int per, float* __restrict__ out);
+__global__ void rot_mean_kernel(const float* __restrict__ R, long r_ss, const float* __restrict__ mu, int mu_per_set, int C, int per,
+                                float* __restrict__ out);
 int chol_np(int C);
 int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st);
 size_t ns_ws_floats(int C, int batch);
@@ -207,89 +208,94 @@ int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg
     return small_gemm(w.Zt, C, (long)cc, w.G1, C, (long)cc, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
 }
 
-// style statistics once, rotated for every iteration:  cov_sr[it][s] = R_it^T cov(S_s) R_it + eps I,  mu_sr = R_it^T mu_s,
+// style statistics once, rotated for every iteration and every ROTATION SET g (G sets: one per style segment when the
+// rotations are shared, one per pastiche segment when every segment has its own, r_ss != 0):
+//   cov_sr[it][g] = R_g,it^T cov(S_s(g)) R_g,it + eps I,   mu_sr[it][g] = R_g,it^T mu_s(g),   s(g) = g or 0
 // and the style-side factor of the mode (chol: U_s = L_s^T; pca: Q_s)
-int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int C, const float* R32, int iters, hipStream_t st,
-                  void* stream) {
+int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int G, int C, const float* R32, long r_ss, int iters,
+                  hipStream_t st, void* stream) {
     const size_t cc = (size_t)C * C;
     int rc;
     if ((rc = optex_linear_stats(style, ns, (long)C * ns, ns, C, Ss, 0, 0.f, w.mu_s, w.cov_s, w.stats_ws, w.stats_ws_bytes, stream)))
         return rc;
-    for (int s = 0; s < Ss; s++) {
-        // tmp[it][s] = cov_s @ R_it   (cov_s symmetric);   cov_sr[it][s] = R_it^T @ tmp + eps I
-        if ((rc = small_gemm(w.cov_s + (size_t)s * cc, C, 0, R32, C, (long)cc, w.tmp_s + (size_t)s * cc, C, (long)(cc * Ss), C, iters,
-                             false, 1.f, nullptr, 0.f, st, false)))
+    for (int g = 0; g < G; g++) {
+        const float* Rg = R32 + (size_t)g * r_ss;
+        const float* cov = w.cov_s + (size_t)(Ss > 1 ? g : 0) * cc;
+        // tmp[it][g] = cov_s @ R_it   (cov_s symmetric);   cov_sr[it][g] = R_it^T @ tmp + eps I
+        if ((rc = small_gemm(cov, C, 0, Rg, C, (long)cc, w.tmp_s + (size_t)g * cc, C, (long)(cc * G), C, iters, false, 1.f, nullptr,
+                             0.f, st, false)))
             return rc;
-        if ((rc = small_gemm(R32, C, (long)cc, w.tmp_s + (size_t)s * cc, C, (long)(cc * Ss), w.cov_sr + (size_t)s * cc, C,
-                             (long)(cc * Ss), C, iters, true, 1.f, nullptr, kEps, st, true)))
+        if ((rc = small_gemm(Rg, C, (long)cc, w.tmp_s + (size_t)g * cc, C, (long)(cc * G), w.cov_sr + (size_t)g * cc, C,
+                             (long)(cc * G), C, iters, true, 1.f, nullptr, kEps, st, true)))
             return rc;
     }
-    hipLaunchKernelGGL(rot_mean_kernel, dim3(iters * Ss), dim3(256), 0, st, R32, w.mu_s, C, Ss, w.mu_sr);
+    hipLaunchKernelGGL(rot_mean_kernel, dim3(iters * G), dim3(256), 0, st, R32, r_ss, w.mu_s, Ss > 1 ? 1 : 0, C, G, w.mu_sr);
     if ((rc = check_launch("rot_mean_kernel"))) return rc;
-    if (mode == MODE_CHOL) return launch_chol_inv(w.cov_sr, (long)cc, C, iters * Ss, w.Us, w.Ls, st);
+    if (mode == MODE_CHOL) return launch_chol_inv(w.cov_sr, (long)cc, C, iters * G, w.Us, w.Ls, st);
     if (mode == MODE_PCA) {
         float *Y, *Z;
-        if ((rc = ns_sqrt(w.cov_sr, (long)cc, C, iters * Ss, kEps, w.ns_buf, &Y, &Z, st))) return rc;
-        return copy_async(w.Ys, Y, (size_t)iters * Ss * cc, st);
+        if ((rc = ns_sqrt(w.cov_sr, (long)cc, C, iters * G, kEps, w.ns_buf, &Y, &Z, st))) return rc;
+        return copy_async(w.Ys, Y, (size_t)iters * G * cc, st);
     }
     return OPTEX_OK;
 }
 
-int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int Ss, int C, const float* R32,
-                const float* Rt32, int iters, const float* content, float strength, int fused, LoopWs& w, void* stream) {
+// G: rotation sets per iteration (prepare_style); r_ss: elements between the rotation sets of two segments (0 = shared)
+int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int Ss, int G, int C, const float* R32,
+                const float* Rt32, long r_ss, int iters, const float* content, float strength, int fused, LoopWs& w, void* stream) {
     hipStream_t st = as_stream(stream);
     const size_t cc = (size_t)C * C;
     const long xs = (long)C * n;
     int rc;
-    if ((rc = prepare_style(mode, w, style, ns, Ss, C, R32, iters, st, stream))) return rc;
+    if ((rc = prepare_style(mode, w, style, ns, Ss, G, C, R32, r_ss, iters, st, stream))) return rc;
     float* cur = x;       // fused path: the affine map cannot run in place, x and y2 take turns
     float* nxt = w.y2;
     for (int it = 0; it < iters; it++) {
         const float* R = R32 + (size_t)it * cc;
         const float* Rt = Rt32 + (size_t)it * cc;
-        const float* mu_sr = w.mu_sr + (size_t)it * Ss * C;
+        const float* mu_sr = w.mu_sr + (size_t)it * G * C;
         if (fused == 0) {
             // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (+ the row sums for the means, in the epilogue)
             bool sums = false;
-            if ((rc = rotate_with_stats(R, 0, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st))) return rc;
+            if ((rc = rotate_with_stats(R, r_ss, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st))) return rc;
             // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I   (statistics of the ROTATED map, like the reference)
             if ((rc = linear_stats_parts(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes,
                                          sums ? w.rs_a : nullptr, w.rs_parts, stream)))
                 return rc;
-            if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, Ss, it, st))) return rc;   // At = T^T
+            if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, G, it, st))) return rc;   // At = T^T
             // histmatch.py:27/34/42,44 + optex.py:175, 115-117:  (T hist_t + mu_sr) @ R^T  evaluated as ONE feature-map GEMM
             //   x = (R T)(y - mu_t) + R mu_sr,   R mu_sr = R R^T mu_s = mu_s,   (R T)^T = T^T R^T = At @ Rt
             // — the same product in another association (a C x C GEMM instead of a second C x n one); the content blend
             // rides in the epilogue as before.
-            if ((rc = small_gemm_nn(w.At, (long)cc, Rt, 0, w.M1, C, n_seg, 1.f, nullptr, 0.f, st))) return rc;
+            if ((rc = small_gemm_nn(w.At, (long)cc, Rt, r_ss, w.M1, C, n_seg, 1.f, nullptr, 0.f, st))) return rc;
             if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream)))
                 return rc;
         } else if (fused == 2) {
             // the literal sequence, three feature-map GEMMs (kept for tests and comparisons)
             // optex.py:170  rotated_pastiche = pastiche_feature @ rotation
-            if ((rc = fgemm(R, 0, x, w.y, C, n, n_seg, nullptr, nullptr, 0, nullptr, 0.f, stream))) return rc;
+            if ((rc = fgemm(R, r_ss, x, w.y, C, n, n_seg, nullptr, nullptr, 0, nullptr, 0.f, stream))) return rc;
             // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I
             if ((rc = optex_linear_stats(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes, stream)))
                 return rc;
-            if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, Ss, it, st))) return rc;
+            if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, G, it, st))) return rc;
             // histmatch.py:27/34/42,44  matched = T @ hist_t + mu_s
-            if ((rc = fgemm(w.At, (long)cc, w.y, w.y2, C, n, n_seg, w.mu_t, mu_sr, Ss > 1 ? C : 0, nullptr, 0.f, stream))) return rc;
+            if ((rc = fgemm(w.At, (long)cc, w.y, w.y2, C, n, n_seg, w.mu_t, mu_sr, G > 1 ? C : 0, nullptr, 0.f, stream))) return rc;
             // optex.py:175 + 115-117  pastiche = matched @ rotation.T ; content blend
-            if ((rc = fgemm(Rt, 0, w.y2, x, C, n, n_seg, nullptr, nullptr, 0, content, strength, stream))) return rc;
+            if ((rc = fgemm(Rt, r_ss, w.y2, x, C, n, n_seg, nullptr, nullptr, 0, content, strength, stream))) return rc;
         } else {
             // Single affine step in un-rotated space, the labelled fast path:
             //   cov(x R) = R^T cov(x) R,   x' = M (x - mu_x) + mu_s   with   M = R T R^T
             // one covariance and ONE feature-map GEMM per iteration instead of three.  small_gemm(L, B) = L^T @ B.
             if ((rc = optex_linear_stats(cur, n, xs, n, C, n_seg, 0, 0.f, w.mu_x, w.cov_t, w.stats_ws, w.stats_ws_bytes, stream)))
                 return rc;
-            if ((rc = small_gemm(w.cov_t, C, (long)cc, R, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
+            if ((rc = small_gemm(w.cov_t, C, (long)cc, R, C, r_ss, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
                 return rc;                                                                   // cov(x) R
-            if ((rc = small_gemm(R, C, 0, w.M1, C, (long)cc, w.Mt, C, (long)cc, C, n_seg, true, 1.f, nullptr, kEps, st, true)))
+            if ((rc = small_gemm(R, C, r_ss, w.M1, C, (long)cc, w.Mt, C, (long)cc, C, n_seg, true, 1.f, nullptr, kEps, st, true)))
                 return rc;                                                                   // R^T cov(x) R + eps I
-            if ((rc = transfer_operators(mode, w, w.Mt, C, n_seg, Ss, it, st))) return rc;   // At = T^T
-            if ((rc = small_gemm(w.At, C, (long)cc, Rt, C, 0, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
+            if ((rc = transfer_operators(mode, w, w.Mt, C, n_seg, G, it, st))) return rc;   // At = T^T
+            if ((rc = small_gemm(w.At, C, (long)cc, Rt, C, r_ss, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
                 return rc;                                                                   // (T^T)^T R^T = T R^T
-            if ((rc = small_gemm(w.M1, C, (long)cc, Rt, C, 0, w.Mt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
+            if ((rc = small_gemm(w.M1, C, (long)cc, Rt, C, r_ss, w.Mt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
                 return rc;                                                                   // (T R^T)^T R^T = R T^T R^T = M^T
             // x' = M (x - mu_x) + mu_s  (R mu_sr = R R^T mu_s = the un-rotated style mean), content blend in the epilogue
             if ((rc = fgemm(w.Mt, (long)cc, cur, nxt, C, n, n_seg, w.mu_x, w.mu_s, Ss > 1 ? C : 0, content, strength, stream)))
@@ -333,8 +339,8 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         return OPTEX_E_ARG;
     }
     if (!linear && fuse_rotations == 2) fuse_rotations = 0;
-    if (r_seg_stride != 0 && (linear || fuse_rotations)) {
-        set_error("optex_ot_loop: per-segment rotations (r_seg_stride != 0) are implemented for cdf / sort with fuse_rotations = 0");
+    if (r_seg_stride != 0 && !linear && fuse_rotations) {
+        set_error("optex_ot_loop: cdf / sort with per-segment rotations (r_seg_stride != 0) run with fuse_rotations = 0 only");
         return OPTEX_E_UNSUPPORTED;
     }
     if (r_seg_stride != 0 && r_seg_stride < (long)iters * C * C) {
@@ -360,7 +366,8 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
     const int rs_seg = r_seg_stride != 0 ? n_seg : src_n_seg;
     w.layout(bump, mode, n, ns, C, n_seg, rs_seg, iters, fuse_rotations);
     if (linear)
-        return linear_loop(mode, x, n, n_seg, style, ns, src_n_seg, C, R32, Rt32, iters, content, strength, fuse_rotations, w, stream);
+        return linear_loop(mode, x, n, n_seg, style, ns, src_n_seg, rs_seg, C, R32, Rt32, r_seg_stride, iters, content, strength,
+                           fuse_rotations, w, stream);
 
     hipStream_t st = as_stream(stream);
     const long xs = (long)C * n, ss = (long)C * ns;

@@ -115,8 +115,8 @@ def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content:
         # one numpy stream per texture: every segment draws its own rotations, like the reference run once per image
         if pooled or len(rng) != s:
             raise ValueError(f"per-texture rotation streams need independent textures and one stream per texture (got {len(rng)} for {s})")
-        if hist_mode not in ("cdf", "sort"):
-            raise NotImplementedError("per-texture rotation sequences are implemented for hist_mode cdf / sort")
+        if hist_mode not in LOOP_MODES or (hist_mode in LINEAR_MODES and c > ops.LINEAR_MAX_C):
+            raise NotImplementedError(f"per-texture rotation sequences need a hist_mode of the fused loop and C <= {ops.LINEAR_MAX_C}")
         R32, Rt32 = rotation.rotations_per_segment(c, iters, x.device, rng)
         if content is not None and content.shape[0] != s:
             content = content.expand(s, c, n).contiguous()
@@ -199,7 +199,7 @@ class OptimalTexture(torch.nn.Module):
         self.index_by_position = index_by_position
         self.style_sync = None  # multi-GPU hook: callable(list of tensors or None) -> list of tensors (dist.py)
         # numpy RandomState for the rotations (None = numpy's global state, like the reference: ONE sequence shared by the
-        # whole batch, optex.py:168-170), or a list of one RandomState per texture (independent=True, cdf / sort): every
+        # whole batch, optex.py:168-170), or a list of one RandomState per texture (independent=True): every
         # texture then draws its own rotations — the batch equals B separate runs of the reference, seed for seed
         self.rng = None
 

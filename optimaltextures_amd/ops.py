@@ -207,7 +207,7 @@ def rotations_from_normals(normals, N, count, device, want64=False):
 def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False):
     """optex.py:112-117, all iterations enqueued by one C call, for every hist_mode; x [S, C, n] (independent segments) is
     updated IN PLACE.  R32 / Rt32: [iters, C, C] shared by all segments (the reference shares R across its batch), or
-    [S, iters, C, C]: one rotation set per segment (cdf / sort).  fuse_rotations = True / 1 (labelled fast paths, fp32
+    [S, iters, C, C]: one rotation set per segment.  fuse_rotations = True / 1 (labelled fast paths, fp32
     round-off differences only): cdf / sort evaluate (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (needs content=None);
     the linear modes run the whole step as one affine map in un-rotated space."""
     lib = _lib.lib()

@@ -18,6 +18,9 @@ for MODE in cdf sort chol; do
   python scripts/summarize_rocprof.py $OUT/prof_$MODE/prof_kernel_trace.csv --warmup 1 --title "bench.py --hist_mode $MODE, 64 textures per step ($STAMP)" --out $OUT/bench_b64_${MODE}_kernel_summary.md > /dev/null 2>&1
   rm -rf $OUT/prof_$MODE
 done
+( timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_pca -o prof -- python bench.py --hist_mode chol --pca --steps 2 --warmup 1 --no_cpu_baseline --other_modes "" > $OUT/prof_pca.log 2>&1; echo "rc=$?" >> $OUT/prof_pca.log )
+python scripts/summarize_rocprof.py $OUT/prof_pca/prof_kernel_trace.csv --warmup 1 --title "bench.py --hist_mode chol --pca (the reference's default flags, independent textures), 64 textures per step ($STAMP)" --out $OUT/bench_b64_pca_kernel_summary.md > /dev/null 2>&1
+rm -rf $OUT/prof_pca
 head -24 $OUT/bench_b64_cdf_kernel_summary.md
 for MODE in cdf sort; do
   for CTR in FETCH_SIZE WRITE_SIZE; do

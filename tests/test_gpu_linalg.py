@@ -189,3 +189,38 @@ def test_driver_linear_modes_use_the_fused_loop(dev):
         for R in Rs:
             w = orc.unrotate_cm(orc.linear_match(orc.rotate_cm(w, R), 1, orc.rotate_cm(sty[0], R), 1, "chol"), R)
         assert np.abs(got[s] - w).max() <= 3 * LIN_TOL * np.abs(w).max()
+
+
+@pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
+@pytest.mark.parametrize("S,C,n,ns,blend,fused", [(3, 32, 1024, 768, False, 0), (2, 23, 400, 300, True, 2), (4, 181, 4096, 3072, False, 0),
+                                                   (2, 64, 2048, 1500, True, 1)])
+def test_linear_modes_per_texture_rotation_streams(dev, mode, S, C, n, ns, blend, fused):
+    """un-shared rotations in the linear modes (optex.py:168 run once per image): texture i of a batch driven by one numpy
+    stream per texture equals the B = 1 run with stream i (to round-off: the split-K partition of the covariance depends on
+    the batch), and the oracle chain with the same rotations"""
+    from optimaltextures_amd import ops, rotation
+    rng = np.random.default_rng(S * C + n)
+    x = relu_feat(rng, S, C, n, scale=2.0, shift=0.3)
+    sty = relu_feat(rng, 1, C, ns, scale=1.5, shift=0.5)
+    content = relu_feat(rng, S, C, n, scale=2.0) if blend else None
+    iters, seeds = 3, [500 + 11 * i for i in range(S)]
+    R, Rt = rotation.rotations_per_segment(C, iters, dev, [np.random.RandomState(sd) for sd in seeds])
+    xd = cu(x, dev)
+    ops.ot_loop(mode, xd, cu(sty, dev), R, Rt, content=cu(content, dev) if blend else None, strength=0.05 if blend else 0.0,
+                fuse_rotations=fused)
+    batch = xd.cpu().numpy()
+    Rh = R.cpu().numpy()
+    for i in range(S):
+        xi = cu(x[i:i + 1], dev)
+        ops.ot_loop(mode, xi, cu(sty, dev), R[i].contiguous(), Rt[i].contiguous(), content=cu(content[i:i + 1], dev) if blend else None,
+                    strength=0.05 if blend else 0.0, fuse_rotations=fused)
+        one = xi.cpu().numpy()[0]
+        assert np.abs(batch[i] - one).max() <= 2e-5 * np.abs(one).max(), f"texture {i}"
+        w = x[i]
+        for it in range(iters):
+            rp, rs = orc.rotate_cm(w, Rh[i, it]), orc.rotate_cm(sty[0], Rh[i, it])
+            w = orc.unrotate_cm(orc.linear_match(rp, 1, rs, 1, mode), Rh[i, it])
+            if blend:
+                w = orc.content_blend(w, content[i], 0.05)
+        assert np.abs(batch[i] - w).max() <= 3 * LIN_TOL * np.abs(w).max(), f"texture {i} vs oracle"
+    assert np.abs(batch[0] - batch[1]).max() > 1e-3 * np.abs(batch).max()
