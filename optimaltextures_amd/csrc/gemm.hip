@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kk < a.K) {
                 const float* p = At + (size_t)kk * a.lda + m;
-                if (VEC && m + 3 < a.M) {
+                if (a.a_vec && m + 3 < a.M) {  // (uniform: the small matrix has its own alignment flag)
                     v = *reinterpret_cast<const float4*>(p);
                 } else {
                     if (m + 0 < a.M) v.x = p[0];
@@ -511,12 +511,12 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     // 2-5 % ahead where it fits exactly (192 < M, K <= 256, multiples of 4), the R-stationary one everywhere else: PCA
     // ranks (M = K = 181: 86 vs 60 TFLOP/s of useful flops), project / unproject (181 x 256: 93 vs 67), 192 x 192 (89 vs 78).
     if (!BPM && !OPM && gemm_rs_enabled && gemm_rs_supported(a, n_cu)) {
-        const bool lds_fits = a.M > 192 && a.K > 192 && a.M % 4 == 0 && vec && hot_shape(a, n_cu) && output_vec(a);
+        const bool lds_fits = a.M > 192 && a.K > 192 && a.M % 4 == 0 && vec && a.a_vec && hot_shape(a, n_cu) && output_vec(a);
         if (!lds_fits || gemm_rs_force) return gemm_rs_launch(a, n_cu, st);
     }
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
-        if (!BPM && !OPM && vec && hot_shape(a, n_cu) && output_vec(a)) {
+        if (!BPM && !OPM && vec && a.a_vec && hot_shape(a, n_cu) && output_vec(a)) {
             a.tiles_m = (a.M + 255) / 256;
             a.tiles_n = (int)(a.n / 128);
             const long long total = (long long)a.tiles_m * a.tiles_n * a.n_seg;
@@ -539,9 +539,11 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);
 }
 
-static bool operands_vec(const GemmArgs& a) {
-    return aligned16(a.At) && a.lda % 4 == 0 && a.at_ss % 4 == 0 && aligned16(a.B) && a.ldb % 4 == 0 && a.b_ss % 4 == 0;
-}
+// 16-byte loads need 16-byte aligned rows — per operand: a ragged PCA rank (lda = k = 181) costs the small matrix its
+// vector loads, not the feature map
+static bool a_operand_vec(const GemmArgs& a) { return aligned16(a.At) && a.lda % 4 == 0 && a.at_ss % 4 == 0; }
+static bool b_operand_vec(const GemmArgs& a) { return aligned16(a.B) && a.ldb % 4 == 0 && a.b_ss % 4 == 0; }
+static bool operands_vec(const GemmArgs& a) { return a_operand_vec(a) && b_operand_vec(a); }
 
 bool gemm_rowstat_supported(const GemmArgs& a) {
     if (a.bsub || a.badd || a.content) return false;
@@ -554,8 +556,10 @@ int gemm_rowstat_parts(long n) { return n % 64 == 0 ? (int)(n / 64) : 0; }
 
 int gemm_tn_launch(GemmArgs& a, int b_layout, int o_layout, hipStream_t st) {
     const bool bpm = b_layout == OPTEX_PIXEL_MAJOR, opm = o_layout == OPTEX_PIXEL_MAJOR;
-    // float4 paths need 16-byte aligned rows on every operand that is accessed with vectors
-    bool vec = operands_vec(a);
+    // float4 paths need 16-byte aligned rows on every operand that is accessed with vectors: the template flag covers the
+    // feature map (and a pixel-major output), the small matrix carries its own (runtime, uniform) flag
+    a.a_vec = a_operand_vec(a) ? 1 : 0;
+    bool vec = b_operand_vec(a);
     if (opm) vec = vec && aligned16(a.O) && a.ldo % 4 == 0 && a.o_ss % 4 == 0;
     const int n_cu = device_cu_count();
     if (!bpm && !opm) return launch_layout<false, false>(a, vec, n_cu, st);

@@ -15,6 +15,7 @@ struct GemmArgs {
     const float* badd; long badd_ss;
     const float* content; float strength;
     int tiles_m, tiles_n;
+    int a_vec;  // At rows take 16-byte loads (set by gemm_tn_launch)
     // optional scaling epilogue of the small C x C products of the linear modes (linalg.hip):
     //   OUT = alpha * alpha_seg[seg] * acc + diag * (m == i)        (epi = 0: untouched, the hot-loop arithmetic)
     // sym = 1 (64 x 64 tiles, square output): the product is symmetric in exact arithmetic — only the tiles on or above
