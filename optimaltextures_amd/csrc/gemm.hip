@@ -508,8 +508,9 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     if (a.sym) return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);  // square tiles: the mirrored store needs BM == BN
     // Channel-major rotations of the hot loop.  Both hot kernels run at the chip's power-managed clock on dense data
     // (profiles/r03_gemm_power_dvfs.md: 2.11-2.13 GHz, MFMA duty 0.74-0.76 either way); the 256 x 128 LDS-tiled kernel is
-    // 2-5 % ahead where it fits exactly (192 < M, K <= 256, multiples of 4), the R-stationary one everywhere else: PCA
-    // ranks (M = K = 181: 86 vs 60 TFLOP/s of useful flops), project / unproject (181 x 256: 93 vs 67), 192 x 192 (89 vs 78).
+    // 2-5 % ahead where it fits exactly (192 < M, K <= 256, multiples of 4), the R-stationary one everywhere else in
+    // 64 < M <= 256, 64 <= K <= 256: PCA ranks (M = K = 181: 86 vs 60 TFLOP/s of useful flops), project / unproject
+    // (181 x 256: 93 vs 67), 192 x 192 (89 vs 78), relu2_1's ranks (k ~ 84 of C = 128).
     if (!BPM && !OPM && gemm_rs_enabled && gemm_rs_supported(a, n_cu)) {
         const bool lds_fits = a.M > 192 && a.K > 192 && a.M % 4 == 0 && vec && a.a_vec && hot_shape(a, n_cu) && output_vec(a);
         if (!lds_fits || gemm_rs_force) return gemm_rs_launch(a, n_cu, st);

@@ -54,7 +54,7 @@ struct RsArgs {
     int segs_per_group;   // segments sharing one matrix: n_seg (at_seg_stride == 0) or 1; gridDim.y = n_seg / segs_per_group
 };
 
-// MT: 16-row tiles per wave (rows per workgroup = 64 MT);  KS: k-steps of 4, 4 (KS - RS_RAG) <= K <= 4 KS: the last RS_RAG
+// MT: 16-row tiles per wave (rows per workgroup = 64 MT: 128 / 192 / 256);  KS: k-steps of 4 (32 / 48 / 64), 4 (KS - RS_RAG) <= K <= 4 KS: the last RS_RAG
 // k-steps test their rows, and a k-step entirely beyond K is branched over (uniform);  EXTRA: bias (badd) and content
 // blend in the epilogue (1), and the operand centring `B[k][i] - bsub[k]` of the linear modes' apply step as well (2:
 // KS more registers, one subtraction per fragment component, the same single rounding as the other kernels)
@@ -270,7 +270,7 @@ bool gemm_rs_supported(const GemmArgs& a, int n_cu) {
     if (a.epi || a.sym) return false;
     if (a.bsub && a.bsub_ss != 0 && a.at_ss == 0) return false;  // a workgroup keeps one matrix AND one centring vector
     if (a.bsub && a.M > 192) return false;  // (four row tiles per wave + the centring ring spill: the LDS-tiled kernel takes these)
-    if (a.M <= 128 || a.M > 256 || a.K <= 128 || a.K > 256) return false;
+    if (a.M <= 64 || a.M > 256 || a.K < 64 || a.K > 256) return false;
     if (a.n % RS_BN != 0 || a.n <= 0) return false;
     if (!rs_aligned16(a.B) || a.ldb % 4 != 0 || a.b_ss % 4 != 0) return false;
     if (!rs_aligned16(a.O) || a.ldo % 4 != 0 || a.o_ss % 4 != 0) return false;
@@ -286,7 +286,7 @@ template <int MT, int KS>
 static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
     const GemmArgs& a = ra.g;
     if (a.bsub) {
-        if constexpr (MT == 3) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2>), grid, dim3(256), 0, st, ra);
+        if constexpr (MT <= 3) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2>), grid, dim3(256), 0, st, ra);
     } else if (a.badd || a.content)
         hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1>), grid, dim3(256), 0, st, ra);
     else if (a.rowstat == 1)
@@ -310,12 +310,19 @@ int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
     ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                    4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
     const dim3 grid((unsigned)gx, (unsigned)groups);
-    // rows: (128, 192] -> three 16-row tiles per wave, (192, 256] -> four; depth: (128, 192] -> 48 k-steps, (192, 256] -> 64
-    const bool m4 = a.M > 192, k64 = a.K > 192;
-    if (m4 && k64) return rs_launch_mk<4, 64>(ra, grid, st);
-    if (m4) return rs_launch_mk<4, 48>(ra, grid, st);
-    if (k64) return rs_launch_mk<3, 64>(ra, grid, st);
-    return rs_launch_mk<3, 48>(ra, grid, st);
+        const int mt = a.M > 192 ? 4 : (a.M > 128 ? 3 : 2);   // rows: (64, 128] / (128, 192] / (192, 256]
+    const int ks = a.K > 192 ? 64 : (a.K > 128 ? 48 : 32);  // k-steps: K in [64, 128] / (128, 192] / (192, 256]
+    switch (mt * 100 + ks) {
+        case 464: return rs_launch_mk<4, 64>(ra, grid, st);
+        case 448: return rs_launch_mk<4, 48>(ra, grid, st);
+        case 432: return rs_launch_mk<4, 32>(ra, grid, st);
+        case 364: return rs_launch_mk<3, 64>(ra, grid, st);
+        case 348: return rs_launch_mk<3, 48>(ra, grid, st);
+        case 332: return rs_launch_mk<3, 32>(ra, grid, st);
+        case 264: return rs_launch_mk<2, 64>(ra, grid, st);
+        case 248: return rs_launch_mk<2, 48>(ra, grid, st);
+        default: return rs_launch_mk<2, 32>(ra, grid, st);
+    }
 }
 
 }  // namespace optex

@@ -26,7 +26,9 @@ def biteq(a, b):
 
 # (M, K): the four instantiations (rows (128,192] / (192,256]  x  depth (128,192] / (192,256]) at their edges and inside
 SHAPES = [(256, 256), (181, 181), (192, 192), (193, 193), (129, 129), (181, 256), (256, 181), (165, 200), (250, 133),
-          (256, 131), (130, 256), (255, 255), (224, 225)]
+          (256, 131), (130, 256), (255, 255), (224, 225),
+          # relu2_1 with PCA (C = 128, k ~ 71-86) and small ranks at relu3_1: rows (64, 128], k-steps [64, 128]
+          (84, 84), (84, 128), (128, 84), (128, 128), (65, 64), (100, 256), (256, 100), (71, 190), (190, 71), (127, 65)]
 
 
 @pytest.mark.parametrize("M,K", SHAPES)
@@ -89,7 +91,7 @@ def test_rs_gemm_nonfinite_rows_beyond_k_do_not_leak(dev):
     assert np.isfinite(got[0]).all() and biteq(got[0], orc.gemm_tn(At, x[0]))
 
 
-@pytest.mark.parametrize("M,K", [(181, 181), (165, 165), (181, 256), (192, 192)])
+@pytest.mark.parametrize("M,K", [(181, 181), (165, 165), (181, 256), (192, 192), (84, 84), (100, 128)])
 def test_rs_gemm_centred_operand_bit_exact(dev, M, K):
     """the apply step of the linear modes at PCA ranks (histmatch.py:27/34/42,44: T @ (hist_t - mu_t) + mu_s): per-segment
     operators, per-segment centring vector and bias, content blend — one subtraction per operand element, one rounding"""
