@@ -1,3 +1,5 @@
+# Rotation GEMM at the hot-loop shape, both hot kernels, three kinds of data, un-profiled and under rocprofv3 --pmc: the source of
+# profiles/r03_gemm_power_dvfs.md (probe binaries: make -C scripts).   gpurun -- bash scripts/gpu_gemm_power.sh
 OUT=gpurun_out/r03_gemm_power
 mkdir -p $OUT
 export TMPDIR=/tmp

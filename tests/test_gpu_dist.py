@@ -61,7 +61,7 @@ a, b = run(False), run(True)
 assert bool((a == b).all()), float((a - b).abs().max())
 # BASELINE config 4's per-GPU shard: 8 independent 512^2 textures, relu3_1, C = 256 (no_pca), the full 5-pass schedule
 # (52 OT iterations), the style side arriving through the RCCL broadcast hook (VERDICT r2 item 1b).
-# MIOpen's fp32 convolutions are not reproducible run to run at these shapes (scripts/dbg: the same encoder call differs
+# MIOpen's fp32 convolutions are not reproducible run to run at these shapes (scripts/miopen_determinism_probe.py: the same encoder call differs
 # by 1e-6 .. 7e-6 from itself, and `cdf` amplifies one ulp to a whole bin within five iterations, SURVEY 0), so two whole
 # forward calls cannot be compared bit for bit.  What the hook must not change is checked exactly where it is exact:
 #   (1) the style side the hook delivers == the style side computed locally, bit for bit, for all five passes, when both
