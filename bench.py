@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="independent textures per GPU per step (16 / 32 / 64 measured: 176 / 183 / 198 textures/s)")
     ap.add_argument("--hist_mode", type=str, default="cdf", choices=["cdf", "sort", "chol", "pca", "sym"])
-    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,pcadefault,ownrotations,refdefaults,assets",
+    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,pcadefault,ownrotations,refdefaults,assets,single",
                     help="one extra step each (N = 1 only); 'fused' = the labelled re-association fast paths, "
                          "'refdefaults' = chol + PCA + pooled batch (the reference's own defaults), 'assets' = the headline "
                          "configuration on the reference's real relu3_1 weights and style/graffiti.jpg (assets/)")
@@ -399,6 +399,23 @@ def main():
                 result["textures_per_s_independent_rotations"] = {
                     "value": round(B / (time.perf_counter() - t0), 3),
                     "config": f"hist_mode={args.hist_mode}, one rotation sequence per texture (rotation group size 1), host threads for the numpy streams: {min(64, os.cpu_count() or 1)}"}
+        if "single" in args.other_modes.split(","):
+            # latency of ONE texture with the reference's default command line (`python optex.py`: B = 1, all five layers,
+            # PCA, hist_mode chol, 500 iterations, 512^2; BASELINE config 2 with chol): launch-bound, not a throughput number
+            with torch.inference_mode():
+                m = OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode="chol", layers=(5, 4, 3, 2, 1)).to(device).eval()
+                lat = []
+                for rep in range(3):
+                    m.rng = otdist.rotation_rng(args.seed, 10 ** 6 + rep)
+                    noise = otdist.texture_noise(10 ** 6 + rep, 1, (3, SIZE, SIZE), device, seed=args.seed)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    m.forward(noise, [style])
+                    torch.cuda.synchronize()
+                    lat.append(time.perf_counter() - t0)
+            result["single_texture_latency_s"] = {
+                "value": round(min(lat[1:]), 4), "first_call_s": round(lat[0], 3),
+                "config": "B = 1, 512^2, relu5_1..relu1_1, PCA on, hist_mode=chol, 493 OT iterations (the reference's default command line), synthetic weights"}
         if "refdefaults" in args.other_modes.split(","):
             # the reference's own defaults for this layer: hist_mode chol, PCA on, --batch POOLED into one
             # distribution (histmatch.py:11,17-18) — not like-for-like with the headline's independent textures
