@@ -26,18 +26,37 @@ LOOP_MODES = ("cdf", "sort", "chol", "pca", "sym")
 
 
 # ------------------------------------------------------------------------------------------------ PCA (optex.py:180-190)
+# How the basis is found (both stay on PyTorch, as the north star scopes the PCA fit):
+#   "gram" (default): right singular vectors = eigenvectors of the C x C Gram matrix a^T a, singular values = the square
+#       roots of its eigenvalues.  The Gram matrix is taken in fp64 on the GPU (one [C, N] x [N, C] product) and the 64..512-
+#       wide symmetric eigenproblem solved by LAPACK on the host (the fit has to synchronise for the data-dependent rank k
+#       anyway).  torch.linalg.svd on ROCm runs rocSOLVER's Jacobi gesvdj on the whole [N, C] matrix: 27 ms per fit at
+#       relu3_1, 84 % of the GPU time of a single-image run with the reference's default flags
+#       (profiles/r03_single_texture_kernel_summary.md); this route is ~1 ms + a 512 KB copy.
+#   "svd": torch.linalg.svd of the [N, C] matrix, the literal counterpart of optex.py:183.
+# Singular vectors are defined up to sign (and up to a rotation inside equal singular values) in either route and in the
+# reference's LAPACK alike; the parity tests align signs before comparing (tests/test_gpu_configs.py).
+PCA_FIT = "gram"
+
+
 def fit_pca_cm(style_cm: Tensor):
     """style_cm [B, C, n] -> (projected [B, k, n], eigvecs [C, k]).  Reference quirks kept: centring by the GLOBAL scalar
     mean, projecting the UNCENTRED tensor, k = first index whose cumulative *singular-value* share exceeds 0.9."""
     b, c, n = style_cm.shape
     a = style_cm.permute(0, 2, 1).reshape(-1, c) - style_cm.mean()
-    _, sing, vh = torch.linalg.svd(a, full_matrices=False)
+    if PCA_FIT == "gram" and style_cm.is_cuda:
+        a64 = a.double()
+        lam, vec = torch.linalg.eigh((a64.t() @ a64).cpu())           # ascending eigenvalues, columns = eigenvectors
+        sing = lam.clamp_min(0).sqrt().flip(0).to(torch.float32)       # singular values, descending (optex.py:183)
+        vh = vec.flip(1).t().to(torch.float32)                         # rows = right singular vectors
+    else:
+        _, sing, vh = torch.linalg.svd(a, full_matrices=False)
     share = torch.cumsum(sing / torch.sum(sing), dim=0)
     k = int((share > 0.9).to(torch.int32).argmax().item())
     if k < 2:
         raise ValueError(f"PCA kept {k} component(s); the rotation needs a dimension greater than 1 "
                          "(the reference fails the same way in special_ortho_group.rvs)")
-    eigvecs = vh[:k].t().contiguous()  # [C, k]
+    eigvecs = vh[:k].t().contiguous().to(style_cm.device)  # [C, k]
     return project_cm(style_cm, eigvecs), eigvecs
 
 

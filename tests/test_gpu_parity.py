@@ -870,9 +870,13 @@ def test_vgg_codec_fused_path_equals_module_path(dev, depth):
 
 
 # ================================================================================================ N1 / N2 "next" rows
-def test_fit_pca_golden(dev, golden):
-    """optex.py:180-190 (quirks: scalar-mean centring, uncentred projection, off-by-one k): same k, same subspace"""
+@pytest.mark.parametrize("route", ["gram", "svd"])
+def test_fit_pca_golden(dev, golden, route, monkeypatch):
+    """optex.py:180-190 (quirks: scalar-mean centring, uncentred projection, off-by-one k): same k, same subspace — by
+    either route to the basis (eigenvectors of the fp64 Gram matrix, the default; torch.linalg.svd of the [N, C] matrix)"""
+    from optimaltextures_amd import driver
     from optimaltextures_amd.driver import fit_pca
+    monkeypatch.setattr(driver, "PCA_FIT", route)
     g = golden("next_rows.npz")
     feats, eig = fit_pca(cu(g["pca_in"], dev))
     assert eig.shape[1] == int(g["pca_k"])
