@@ -28,11 +28,12 @@ LOOP_MODES = ("cdf", "sort", "chol", "pca", "sym")
 # ------------------------------------------------------------------------------------------------ PCA (optex.py:180-190)
 # How the basis is found (both stay on PyTorch, as the north star scopes the PCA fit):
 #   "gram" (default): right singular vectors = eigenvectors of the C x C Gram matrix a^T a, singular values = the square
-#       roots of its eigenvalues.  The Gram matrix is taken in fp64 on the GPU (one [C, N] x [N, C] product) and the 64..512-
-#       wide symmetric eigenproblem solved by LAPACK on the host (the fit has to synchronise for the data-dependent rank k
-#       anyway).  torch.linalg.svd on ROCm runs rocSOLVER's Jacobi gesvdj on the whole [N, C] matrix: 27 ms per fit at
-#       relu3_1, 84 % of the GPU time of a single-image run with the reference's default flags
-#       (profiles/r03_single_texture_kernel_summary.md); this route is ~1 ms + a 512 KB copy.
+#       roots of its eigenvalues.  The Gram matrix is taken in fp64 (a batched split-K product: rocBLAS has no split-K for a
+#       64 x 64 x 196608 dgemm) and torch.linalg.eigh solves the 64..512-wide symmetric problem on the device in fp64.
+#       torch.linalg.svd on ROCm runs rocSOLVER's Jacobi gesvdj on the whole [N, C] matrix — thousands of tiny launches,
+#       50 / 36 / 78 ms per fit at relu3_1 / 2_1 / 1_1 (scripts/pca_fit_probe.py), 84 % of the GPU time of a single-image
+#       run with the reference's default flags (profiles/r03_single_texture_kernel_summary.md); this route takes 8 / 4 / 6 ms.
+#       (Host LAPACK would take 4 ms on one thread but 150 ms on the 128 threads torch picks on the GPU box's 256-core host.)
 #   "svd": torch.linalg.svd of the [N, C] matrix, the literal counterpart of optex.py:183.
 # Singular vectors are defined up to sign (and up to a rotation inside equal singular values) in either route and in the
 # reference's LAPACK alike; the parity tests align signs before comparing (tests/test_gpu_configs.py).
@@ -46,7 +47,17 @@ def fit_pca_cm(style_cm: Tensor):
     a = style_cm.permute(0, 2, 1).reshape(-1, c) - style_cm.mean()
     if PCA_FIT == "gram" and style_cm.is_cuda:
         a64 = a.double()
-        lam, vec = torch.linalg.eigh((a64.t() @ a64).cpu())           # ascending eigenvalues, columns = eigenvectors
+        rows = a64.shape[0]
+        chunk = 4096
+        full = rows // chunk
+        gram = torch.zeros((c, c), dtype=torch.float64, device=a.device)
+        if full:
+            a3 = a64[:full * chunk].view(full, chunk, c)
+            gram += torch.bmm(a3.transpose(1, 2), a3).sum(0)
+        if rows > full * chunk:
+            tail = a64[full * chunk:]
+            gram += tail.t() @ tail
+        lam, vec = torch.linalg.eigh(gram)                               # ascending eigenvalues, columns = eigenvectors
         sing = lam.clamp_min(0).sqrt().flip(0).to(torch.float32)       # singular values, descending (optex.py:183)
         vh = vec.flip(1).t().to(torch.float32)                         # rows = right singular vectors
     else:
