@@ -18,7 +18,9 @@
 namespace optex {
 
 // BK = K-chunk staged per LDS buffer (BK / 2 MFMA steps of k = 2); the block has WGM x WGN waves (m x n)
-template <int BM, int BN, int BK, int WGM, int WGN, bool BPM, bool OPM, bool VEC>
+// VEC: 16-byte accesses on the feature map (and a pixel-major output); AVEC: on the small matrix (its own alignment: a
+// ragged PCA rank, lda = k = 181, costs the matrix its vector loads, not the feature map)
+template <int BM, int BN, int BK, int WGM, int WGN, bool BPM, bool OPM, bool VEC, bool AVEC = VEC>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kk < a.K) {
                 const float* p = At + (size_t)kk * a.lda + m;
-                if (a.a_vec && m + 3 < a.M) {  // (uniform: the small matrix has its own alignment flag)
+                if (AVEC && m + 3 < a.M) {
                     v = *reinterpret_cast<const float4*>(p);
                 } else {
                     if (m + 0 < a.M) v.x = p[0];
@@ -468,8 +470,10 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
     }
     ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                    4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
-    if (vec)
+    if (vec && a.a_vec)
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WGM, WGN, BPM, OPM, true>), dim3((unsigned)total), dim3(NT), 0, st, a);
+    else if (vec)
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WGM, WGN, BPM, OPM, true, false>), dim3((unsigned)total), dim3(NT), 0, st, a);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WGM, WGN, BPM, OPM, false>), dim3((unsigned)total), dim3(NT), 0, st, a);
     return check_launch("gemm_tn_kernel");
