@@ -51,3 +51,20 @@ for n, c in [(12288, 256), (49152, 128), (196608, 64)]:
             print("  eigh host, %2d thread(s)       %8.2f ms" % (k, timed(lambda: torch.linalg.eigh(gc))))
     print("  eigh device fp64              %8.2f ms" % timed(lambda: torch.linalg.eigh(g)))
     print("  eigh device fp32              %8.2f ms" % timed(lambda: torch.linalg.eigh(g.float())))
+
+# all 25 fits of a five-layer, five-pass run at once: device eigh one after the other against host LAPACK, one thread per
+# matrix on a thread pool (what OptimalTexture.prefetch_style_sides can do, since the style side does not depend on the pastiche)
+from concurrent.futures import ThreadPoolExecutor
+grams = []
+for cdim in (64, 128, 256, 512, 512):
+    x = torch.randn(4096, cdim, device=dev, dtype=torch.float64)
+    grams += [(x.t() @ x) for _ in range(5)]
+print("25 device eigh, sequential        %8.2f ms" % timed(lambda: [torch.linalg.eigh(g) for g in grams], reps=3))
+host = [g.cpu() for g in grams]
+pool = ThreadPoolExecutor(max_workers=25)
+for lim in (1, 2, 4):
+    with threadpool_limits(limits=lim):
+        print("25 host eigh on a pool, %d BLAS thread(s) each %8.2f ms" % (lim, timed(lambda: list(pool.map(torch.linalg.eigh, host)), reps=3)))
+with threadpool_limits(limits=1):
+    print("one 512 x 512 host eigh, 1 thread  %8.2f ms" % timed(lambda: torch.linalg.eigh(host[-1]), reps=3))
+print("one 512 x 512 device eigh          %8.2f ms" % timed(lambda: torch.linalg.eigh(grams[-1]), reps=3))
