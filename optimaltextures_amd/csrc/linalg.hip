@@ -147,9 +147,148 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const float* __restrict_
     }
 }
 
+// The same factorization with the panel update on the matrix cores and a barrier-free panel solve (round 3).
+//   phase A: acc[r][c] = A[r][j0 + c] - sum_{k < j0} row_r[k] * L[j0 + c][k] is a GEMM of the finished columns against the
+//     staged panel rows: per 32-row group one v_mfma_f32_32x32x2_f32 per two k (operand A = pan[k][c] from LDS, operand B =
+//     -row[k] from L2, coalesced), the same k-ordered fma chain as the VALU loop of chol_inv_kernel — which spent its time on
+//     eight broadcast ds_read_b128 per 32 fmas.  The MFMA leaves a row's 32 values on lanes l and l + 32; sixteen
+//     v_permlane32_swap hand every thread its own row.
+//   phase B: the 32 x 32 diagonal block is factored by the 32 lanes that own its rows with wave-level synchronisation only;
+//     after ONE workgroup barrier every thread solves its row against the finished block without further barriers
+//     (chol_inv_kernel: two workgroup barriers per column, 64 per panel).
+typedef float chx16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(1024) void chol_inv2_kernel(const float* __restrict__ A, long a_ss, int C, int NP,
+                                                          float* __restrict__ U, float* __restrict__ Linv) {
+    extern __shared__ __align__(16) float ch_smem[];
+    float* pan = ch_smem;                                     // [j0][32]: U[k][j0 .. j0+31] for the finished columns k < j0
+    float* dg = ch_smem + (size_t)(NP - CH_NB) * CH_NB;           // [32][33]: the diagonal block of the current panel
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const float* Ab = A + (size_t)b * a_ss;
+    float* Ub = U + (size_t)b * NP * NP;
+    float* Wb = Linv + (size_t)b * NP * NP;
+    // 32-row groups: group g holds rows [32 g, 32 g + 32) of L for g < NP / 32, rows of W = L^-T behind them; a wave's two
+    // lane halves are groups 2 wave and 2 wave + 1 (NP is a multiple of 32, not of 64: the halves may differ in role)
+    const int ngl = NP / CH_NB;
+    const int g0 = 2 * wave, g1 = 2 * wave + 1;
+    const bool roleL0 = g0 < ngl, roleL1 = g1 < ngl;
+    const int base0 = (roleL0 ? g0 : g0 - ngl) * CH_NB, base1 = (roleL1 ? g1 : g1 - ngl) * CH_NB;
+    const bool roleL = h ? roleL1 : roleL0;
+    const int r = (h ? base1 : base0) + l31;               // this thread's row of L, or of W
+
+    for (int j0 = 0; j0 < NP; j0 += CH_NB) {
+        for (int idx = tid; idx < j0 * (CH_NB / 4); idx += blockDim.x) {
+            const int k = idx / (CH_NB / 4), c4 = (idx % (CH_NB / 4)) * 4;
+            *reinterpret_cast<float4*>(pan + k * CH_NB + c4) = *reinterpret_cast<const float4*>(Ub + (size_t)k * NP + j0 + c4);
+        }
+        __syncthreads();
+        // ---- phase A.  MFMA C/D layout: lane (j = lane & 31, h) holds D[i][j] for i = (q & 3) + 8 (q >> 2) + 4 h, q = 0..15;
+        //      here i = panel column c, j = row of the group.  X: group 0 of the wave, Y: group 1.
+        chx16 X, Y;
+        {
+            // initial values in that layout: A[row][col] (symmetric: read row `col`, contiguous over the lanes) for L rows,
+            // the identity for W rows and for the padding.  Unconditional loads at clamped addresses + bit masks: 32 guarded
+            // loads cost a branch and a wait each.
+            const int r0 = base0 + l31, r1 = base1 + l31;
+            const unsigned in0 = (roleL0 && r0 < C) ? 0xffffffffu : 0u, in1 = (roleL1 && r1 < C) ? 0xffffffffu : 0u;
+            const float* a0 = Ab + (r0 < C ? r0 : 0);
+            const float* a1 = Ab + (r1 < C ? r1 : 0);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int col = j0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const unsigned cm = col < C ? 0xffffffffu : 0u;
+                const size_t off = (size_t)(col < C ? col : 0) * C;
+                const unsigned v0 = __float_as_uint(a0[off]), v1 = __float_as_uint(a1[off]);
+                const unsigned i0 = r0 == col ? 0x3f800000u : 0u, i1 = r1 == col ? 0x3f800000u : 0u;
+                X[q] = __uint_as_float((v0 & in0 & cm) | (i0 & ~(in0 & cm)));
+                Y[q] = __uint_as_float((v1 & in1 & cm) | (i1 & ~(in1 & cm)));
+            }
+        }
+        {
+            // a group of L rows takes part while it is not finished; W[i][k] = 0 for k < i: a group of W rows starts at its
+            // first row and takes part once the panel reaches it
+            const bool act0 = roleL0 ? (base0 + CH_NB - 1 >= j0) : (base0 < j0 + CH_NB);
+            const bool act1 = roleL1 ? (base1 + CH_NB - 1 >= j0) : (base1 < j0 + CH_NB);
+            const int kb0 = roleL0 ? 0 : base0, kb1 = roleL1 ? 0 : base1;
+            const float* s0 = (roleL0 ? Ub : Wb) + base0 + l31;
+            const float* s1 = (roleL1 ? Ub : Wb) + base1 + l31;
+            const int kmin = !act0 ? kb1 : (!act1 ? kb0 : (kb0 < kb1 ? kb0 : kb1));
+            if (act0 || act1) {
+                // (all bounds are multiples of 32: four k pairs per trip, their twelve operands in flight together — one pair
+                // per trip waits for an L2 round trip in front of every MFMA)
+                for (int k = kmin; k < j0; k += 8) {
+                    const bool on0 = act0 && k >= kb0, on1 = act1 && k >= kb1;
+                    float a[4], b0[4], b1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        a[u] = pan[(k + 2 * u + h) * CH_NB + l31];
+                        b0[u] = on0 ? s0[(size_t)(k + 2 * u + h) * NP] : 0.f;
+                        b1[u] = on1 ? s1[(size_t)(k + 2 * u + h) * NP] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (on0) X = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], -b0[u], X, 0, 0, 0);
+                        if (on1) Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], -b1[u], Y, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // hand the rows to their threads: after the swap X[q] is column (q & 3) + 8 (q >> 2) and Y[q] that column + 4 of THIS
+        // thread's row, on every lane (v_permlane32_swap exchanges X's upper 32 lanes with Y's lower 32)
+        float acc[CH_NB];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[q]), __float_as_uint(Y[q]), false, false);
+            acc[(q & 3) + 8 * (q >> 2)] = __uint_as_float(sw[0]);
+            acc[(q & 3) + 8 * (q >> 2) + 4] = __uint_as_float(sw[1]);
+        }
+        // ---- phase B, step 1: the diagonal block, by the 32 lanes that own rows j0 .. j0 + 31 (wave-level synchronisation:
+        //      the LDS operations of one wave execute in order)
+        const int gd = j0 / CH_NB;
+        if (wave == (gd >> 1)) {
+            const bool mine = h == (gd & 1);
+            float y[CH_NB];
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++) {
+                float t = acc[c];
+#pragma unroll
+                for (int k = 0; k < c; k++) t = __builtin_fmaf(-y[k], dg[c * (CH_NB + 1) + k], t);
+                if (mine && l31 == c) dg[c * (CH_NB + 1) + c] = sqrtf(t);
+                asm volatile("" ::: "memory");  // (one wave: its LDS operations execute in program order; the compiler must not
+                y[c] = __fdiv_rn(t, dg[c * (CH_NB + 1) + c]);  //  keep dg in registers across these points)
+                if (mine && l31 > c) dg[l31 * (CH_NB + 1) + c] = y[c];
+                asm volatile("" ::: "memory");
+            }
+        }
+        __syncthreads();
+        // ---- step 2: every row against the finished block, no barrier
+        float x[CH_NB];
+        const int rb = r - j0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            float t = acc[c];
+#pragma unroll
+            for (int k = 0; k < c; k++) t = __builtin_fmaf(-x[k], dg[c * (CH_NB + 1) + k], t);
+            const float d = dg[c * (CH_NB + 1) + c];
+            x[c] = (roleL && rb == c) ? d : __fdiv_rn(t, d);
+        }
+        float* dst = roleL ? Ub : Wb;
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) {
+            const int row = j0 + c;
+            const bool keep = roleL ? (r >= row) : (r <= row);
+            dst[(size_t)row * NP + r] = keep ? x[c] : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
 static size_t chol_lds_bytes(int NP) { return ((size_t)(NP - CH_NB) * CH_NB + CH_NB * (CH_NB + 1)) * sizeof(float); }
 
 int chol_np(int C) { return (C + CH_NB - 1) / CH_NB * CH_NB; }
+
+bool chol_use_mfma = true;  // (internal, not ABI: scripts/chol_probe.hip times the two kernels against each other)
 
 // A [batch] (C x C, stride a_ss) -> U, Linv [batch, NP, NP]
 int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st) {
@@ -167,6 +306,9 @@ int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float
     if (lds > attr_lds[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chol_inv_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(chol_inv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds);
         if (e != hipSuccess) {
             set_error("chol_inv_kernel: cannot reserve %zu bytes of LDS for C = %d: %s", lds, C, hipGetErrorString(e));
             return OPTEX_E_LAUNCH;
@@ -175,7 +317,12 @@ int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float
     }
     // 2/3 C^3 flop for the factor + inverse; reads A, writes two triangles
     ProfScope prof(KC_CHOL, st, (2.0 / 3.0) * (double)C * C * C * batch, 12.0 * (double)C * C * batch);
-    hipLaunchKernelGGL(chol_inv_kernel, dim3(batch), dim3(2 * NP), lds, st, A, a_ss, C, NP, U, Linv);
+    // the two kernels compute the same fma chains (bit-identical outputs, scripts/chol_probe.hip); the MFMA panel update pays
+    // from three panels on: 1.08x at C = 100, 1.24x at 256, 1.38x at 512 (batch 64), 0.78x at a single panel
+    if (chol_use_mfma && NP >= 3 * CH_NB)
+        hipLaunchKernelGGL(chol_inv2_kernel, dim3(batch), dim3(2 * NP), lds, st, A, a_ss, C, NP, U, Linv);
+    else
+        hipLaunchKernelGGL(chol_inv_kernel, dim3(batch), dim3(2 * NP), lds, st, A, a_ss, C, NP, U, Linv);
     return check_launch("chol_inv_kernel");
 }
 
