@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 5
+#define OPTEX_ABI_VERSION 6
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -88,6 +88,15 @@ int optex_cdf_match(const float* target, long ldt, long t_seg_stride, long nt,
                     const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
                     int C, int n_seg, float* out, long ldo, long o_seg_stride,
                     void* ws, size_t ws_bytes, float* dbg, void* stream);
+
+/* histmatch.py:49 `cdf_match(target, source, bins)` with the bin count free (ABI 6).  Every caller inside the reference leaves
+ * bins at 256 (optex_cdf_match above, the hot path); this entry serves a direct call with another value.  Same arguments and
+ * layout as optex_cdf_match; one workgroup per column does the whole function.  bins >= 1. */
+size_t optex_cdf_bins_ws_bytes(int C, int n_seg, int bins);
+int optex_cdf_match_bins(const float* target, long ldt, long t_seg_stride, long nt,
+                         const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
+                         int C, int n_seg, int bins, float* out, long ldo, long o_seg_stride,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K6  sort mode — exact 1-D optimal transport per rotated column (north-star addition; there

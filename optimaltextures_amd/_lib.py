@@ -7,7 +7,7 @@ import torch  # imported BEFORE the CDLL so the library binds to the HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liboptex_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 CHANNEL_MAJOR, PIXEL_MAJOR = 0, 1
 
 _c = ctypes
@@ -24,6 +24,8 @@ SIGNATURES = {
     "optex_interp": (_I, [_P, _L, _P, _P, _L, _P, _P]),
     "optex_cdf_ws_bytes": (_SZ, [_I, _I]),
     "optex_cdf_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _P, _P]),
+    "optex_cdf_bins_ws_bytes": (_SZ, [_I, _I, _I]),
+    "optex_cdf_match_bins": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _I, _P, _L, _L, _P, _SZ, _P]),
     "optex_sort_ws_bytes": (_SZ, [_L, _I, _I]),
     "optex_sort_columns": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _SZ, _P]),
     "optex_sort_match_ws_bytes": (_SZ, [_L, _L, _I, _I, _I]),

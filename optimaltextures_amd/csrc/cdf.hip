@@ -342,6 +342,140 @@ __global__ __launch_bounds__(256) void cdf_apply_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ any bin count
+// histmatch.py:49-69 with the reference's third argument `bins` left free (every caller inside the reference keeps 256, the
+// kernels above; this one serves a direct cdf_match(target, source, bins) call).  One 256-thread workgroup per column does the
+// whole function: joint range, both histograms, both CDFs, the remapped CDF and the final interpolation.  The six per-column
+// arrays of `bins` words live in LDS up to kBinsLds bins and in the caller's workspace (L2-resident) beyond that.
+constexpr int kBinsLds = 2048;
+
+// cdf[k] = cumsum(h)[k] / cumsum(h)[-1] as torch does it in fp32: integer prefix sums are exact (and equal) below 2^24,
+// beyond that the sequential fp32 accumulation is replayed
+__device__ void hist_to_cdf(const unsigned* h, float* cdf, int bins, unsigned* part) {
+    const int i = threadIdx.x, per = (bins + 255) / 256;
+    const int b = i * per < bins ? i * per : bins, e = b + per < bins ? b + per : bins;
+    unsigned local = 0;
+    for (int k = b; k < e; k++) local += h[k];
+    __syncthreads();
+    part[i] = local;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned a = (i >= off) ? part[i - off] : 0u;
+        __syncthreads();
+        part[i] += a;
+        __syncthreads();
+    }
+    const unsigned total = part[255];
+    if (total < (1u << 24)) {
+        unsigned run = part[i] - local;
+        const float tl = (float)total;
+        for (int k = b; k < e; k++) {
+            run += h[k];
+            cdf[k] = __fdiv_rn((float)run, tl);
+        }
+    } else {
+        if (i == 0) {
+            float acc = 0.f;
+            for (int k = 0; k < bins; k++) {
+                acc = acc + (float)h[k];
+                cdf[k] = acc;
+            }
+        }
+        __syncthreads();
+        const float tl = cdf[bins - 1];
+        __syncthreads();
+        for (int k = b; k < e; k++) cdf[k] = __fdiv_rn(cdf[k], tl);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void cdf_bins_kernel(const float* __restrict__ target, long ldt, long tss, long nt,
+                                                       const float* __restrict__ source, long lds, long sss, long ns,
+                                                       int src_n_seg, int C, int bins, float* gws, float* __restrict__ out,
+                                                       long ldo, long oss) {
+    extern __shared__ float dyn[];
+    __shared__ float slo[4], shi[4];
+    __shared__ unsigned part[256];
+    const int col = blockIdx.x, seg = col / C, c = col % C;
+    const float* t = target + (size_t)seg * tss + (size_t)c * ldt;
+    const float* s = source + (size_t)((src_n_seg == 1) ? 0 : seg) * sss + (size_t)c * lds;
+    float* o = out + (size_t)seg * oss + (size_t)c * ldo;
+    float* base = (bins <= kBinsLds) ? dyn : gws + (size_t)col * 6 * bins;
+    unsigned *ht = reinterpret_cast<unsigned*>(base), *hs = ht + bins;
+    float *edges = base + 2 * (size_t)bins, *tc = edges + bins, *sc = tc + bins, *rm = sc + bins;
+
+    // histmatch.py:52-53 joint range
+    float lo = INFINITY, hi = -INFINITY;
+    for (long i = threadIdx.x; i < nt; i += 256) {
+        lo = fminf(lo, t[i]);
+        hi = fmaxf(hi, t[i]);
+    }
+    for (long i = threadIdx.x; i < ns; i += 256) {
+        lo = fminf(lo, s[i]);
+        hi = fmaxf(hi, s[i]);
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    for (int k = threadIdx.x; k < 2 * bins; k += 256) ht[k] = 0u;
+    __syncthreads();
+    lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+    hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+
+    // histmatch.py:55-56 torch.histc(x, bins, lo, hi)
+    float hl = lo, hu = hi;
+    if (hl == hu) {
+        hl -= 1.0f;
+        hu += 1.0f;
+    }
+    const float range = hu - hl, fbins = (float)bins;
+    for (int which = 0; which < 2; which++) {
+        const float* x = which ? s : t;
+        const long n = which ? ns : nt;
+        unsigned* h = which ? hs : ht;
+        for (long i = threadIdx.x; i < n; i += 256) {
+            const float v = x[i];
+            if (!(v >= hl && v <= hu)) continue;
+            int pos = (int)__fdiv_rn((v - hl) * fbins, range);
+            pos = pos > bins - 1 ? bins - 1 : pos;
+            atomicAdd(&h[pos], 1u);
+        }
+    }
+    __syncthreads();
+    // histmatch.py:58-65
+    hist_to_cdf(ht, tc, bins, part);
+    hist_to_cdf(hs, sc, bins, part);
+    const float step = __fdiv_rn(hi - lo, fbins);
+    const int half = (bins + 1) / 2;
+    for (int k = threadIdx.x; k < bins; k += 256) {
+        const int i = k + 1;  // torch.linspace(lo, hi, bins + 1)[1:]
+        edges[k] = (i < half) ? __fmaf_rn(step, (float)i, lo) : __fmaf_rn(-step, (float)(bins - i), hi);
+    }
+    __syncthreads();
+    // histmatch.py:67 remapped_cdf = interp(target_cdf, source_cdf, bin_edges)
+    for (int k = threadIdx.x; k < bins; k += 256) {
+        const float x = tc[k];
+        int idx = lower_bound_f(sc, bins, x);
+        idx = idx > bins - 1 ? bins - 1 : idx;
+        rm[k] = interp_eval(x, idx, sc, edges, bins);
+    }
+    __syncthreads();
+    // histmatch.py:68 interp(target_channel, bin_edges, remapped_cdf); the search starts at the histogram bin and is then made
+    // exact (idx = searchsorted_left(edges, x)) by the two walks
+    const float seed = (hi - lo > 0.f) ? fbins / (hi - lo) : 0.f;
+    for (long i = threadIdx.x; i < nt; i += 256) {
+        const float x = t[i];
+        const float f = (x - lo) * seed;
+        int idx = (f >= 0.f) ? ((f < (float)(bins - 1)) ? (int)f : bins - 1) : 0;
+        while (idx > 0 && edges[idx - 1] >= x) idx--;
+        while (idx < bins - 1 && !(edges[idx] >= x)) idx++;
+        o[i] = interp_eval(x, idx, edges, rm, bins);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ generic interp
 __global__ void interp_kernel(const float* __restrict__ x, long nx, const float* __restrict__ xp,
                               const float* __restrict__ fp, int np_, float* __restrict__ out) {
@@ -528,4 +662,30 @@ extern "C" int optex_cdf_match(const float* target, long ldt, long t_seg_stride,
     if (int rc = check_ws("optex_cdf_match", ws, ws_bytes, optex_cdf_ws_bytes(C, n_seg))) return rc;
     return cdf_match_impl(target, ldt, t_seg_stride, nt, source, lds, s_seg_stride, ns, src_n_seg, C, n_seg, out, ldo,
                           o_seg_stride, ws, dbg, as_stream(stream));
+}
+
+extern "C" size_t optex_cdf_bins_ws_bytes(int C, int n_seg, int bins) {
+    if (bins <= kBinsLds) return 256;
+    return (size_t)6 * sizeof(float) * (size_t)bins * (size_t)C * (size_t)n_seg;
+}
+
+extern "C" int optex_cdf_match_bins(const float* target, long ldt, long t_seg_stride, long nt, const float* source, long lds,
+                                    long s_seg_stride, long ns, int src_n_seg, int C, int n_seg, int bins, float* out,
+                                    long ldo, long o_seg_stride, void* ws, size_t ws_bytes, void* stream) {
+    if (!target || !source || !out || !ws || nt <= 0 || ns <= 0 || C <= 0 || n_seg <= 0 || ldt < nt || lds < ns ||
+        ldo < nt || bins <= 0) {
+        set_error("optex_cdf_match_bins: bad argument (nt=%ld ns=%ld C=%d n_seg=%d bins=%d)", nt, ns, C, n_seg, bins);
+        return OPTEX_E_ARG;
+    }
+    if (src_n_seg != 1 && src_n_seg != n_seg) {
+        set_error("optex_cdf_match_bins: source has %d segments, expected 1 or %d", src_n_seg, n_seg);
+        return OPTEX_E_ARG;
+    }
+    if (int rc = check_ws("optex_cdf_match_bins", ws, ws_bytes, optex_cdf_bins_ws_bytes(C, n_seg, bins))) return rc;
+    const int ncols = C * n_seg;
+    const size_t dyn = bins <= kBinsLds ? (size_t)6 * sizeof(float) * bins : 0;
+    ProfScope prof(KC_APPLY, as_stream(stream), 0.0, (16.0 * (double)nt + 8.0 * (double)ns) * ncols);
+    hipLaunchKernelGGL(cdf_bins_kernel, dim3(ncols), dim3(256), dyn, as_stream(stream), target, ldt, t_seg_stride, nt, source,
+                       lds, s_seg_stride, ns, src_n_seg, C, bins, static_cast<float*>(ws), out, ldo, o_seg_stride);
+    return check_launch("cdf_bins_kernel");
 }

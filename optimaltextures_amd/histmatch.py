@@ -105,8 +105,10 @@ def hist_match(target: Tensor, source: Tensor, mode: str = "chol", eps: float = 
 
 def cdf_match(target: Tensor, source: Tensor, bins: int = 256):
     """target [C, Nt], source [C, Ns] -> [C, Nt]  (histmatch.py:49-69)"""
-    if bins != ops.BINS:
-        raise NotImplementedError("the HIP path implements bins=256, the only value the reference ever passes")
+    if bins != ops.BINS:  # no caller inside the reference; one workgroup per column (optex_cdf_match_bins)
+        if int(bins) != bins or bins < 1:
+            raise ValueError(f"bins must be a positive integer, got {bins!r}")
+        return ops.cdf_match_bins_seg(Seg.of(target.contiguous()[None]), Seg.of(source.contiguous()[None]), int(bins))[0]
     return ops.cdf_match_seg(Seg.of(target.contiguous()[None]), Seg.of(source.contiguous()[None]))[0]
 
 

@@ -111,6 +111,18 @@ def cdf_match_seg(t: Seg, s: Seg, out: Seg = None, debug=False):
     return out.t
 
 
+def cdf_match_bins_seg(t: Seg, s: Seg, bins: int, out: Seg = None):
+    """histmatch.py:49-69 with the reference's `bins` argument free (optex_cdf_match_bins)"""
+    lib = _lib.lib()
+    assert t.C == s.C
+    if out is None:
+        out = Seg.of(torch.empty((t.S, t.C, t.n), dtype=torch.float32, device=t.t.device))
+    ws = workspace(lib.optex_cdf_bins_ws_bytes(t.C, t.S, int(bins)), t.t.device)
+    check(lib.optex_cdf_match_bins(ptr(t.t), t.ld, t.ss, t.n, ptr(s.t), s.ld, s.ss, s.n, s.S, t.C, t.S, int(bins), ptr(out.t),
+                                   out.ld, out.ss, ptr(ws), ws.numel(), stream_ptr()))
+    return out.t
+
+
 def sort_columns(x, want_keys=True, want_idx=True):
     lib = _lib.lib()
     S, C, n = x.shape

@@ -316,6 +316,73 @@ static void cdf_channel(const float* t, long nt, const float* s, long ns, float*
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * histmatch.py:49-69 with any `bins` (the reference's third argument; every caller in the reference leaves it at 256).
+ * Same statements as above with the bin count as a variable: torch.histc(x, bins, lo, hi), torch.linspace(lo, hi, bins + 1)
+ * (step = (hi - lo) / bins, first half fma(step, i, lo), second half fma(-step, bins - i, hi), halfway = (bins + 1) / 2),
+ * cumsum / last, the two interp calls.  Pinned by tests/golden/cdf_match_bins.npz (reference outputs for several bins).
+ * ---------------------------------------------------------------------------------------------- */
+static void cdf_channel_bins(const float* t, long nt, const float* s, long ns, int bins, float* out, float* work) {
+    float lo = t[0], hi = t[0];
+    for (long i = 0; i < nt; i++) {
+        lo = t[i] < lo ? t[i] : lo;
+        hi = t[i] > hi ? t[i] : hi;
+    }
+    for (long i = 0; i < ns; i++) {
+        lo = s[i] < lo ? s[i] : lo;
+        hi = s[i] > hi ? s[i] : hi;
+    }
+    float *ht = work, *hs = ht + bins, *e = hs + bins, *tc = e + bins + 1, *sc = tc + bins, *rm = sc + bins;
+    for (int which = 0; which < 2; which++) {
+        float* h = which ? hs : ht;
+        const float* x = which ? s : t;
+        const long n = which ? ns : nt;
+        float l = lo, u = hi;
+        for (int i = 0; i < bins; i++) h[i] = 0.0f;
+        if (l == u) {
+            l -= 1.0f;
+            u += 1.0f;
+        }
+        const float range = u - l;
+        for (long i = 0; i < n; i++) {
+            const float v = x[i];
+            if (!(v >= l && v <= u)) continue;
+            const float scaled = (v - l) * (float)bins;
+            long pos = (long)(scaled / range);
+            if (pos == bins) pos = bins - 1;
+            h[pos] += 1.0f;
+        }
+    }
+    const float step = (hi - lo) / (float)bins;
+    for (int i = 0; i <= bins; i++) e[i] = (i < (bins + 1) / 2) ? fmaf(step, (float)i, lo) : fmaf(-step, (float)(bins - i), hi);
+    const float* edges = e + 1;
+    float acc = 0.0f;
+    for (int i = 0; i < bins; i++) {
+        acc += ht[i];
+        tc[i] = acc;
+    }
+    const float tl = tc[bins - 1];
+    for (int i = 0; i < bins; i++) tc[i] = tc[i] / tl;
+    acc = 0.0f;
+    for (int i = 0; i < bins; i++) {
+        acc += hs[i];
+        sc[i] = acc;
+    }
+    const float sl = sc[bins - 1];
+    for (int i = 0; i < bins; i++) sc[i] = sc[i] / sl;
+    orc_interp(tc, bins, sc, edges, bins, rm);
+    orc_interp(t, nt, edges, rm, bins, out);
+}
+
+void orc_cdf_match_bins(const float* t, long ldt, long nt, const float* s, long lds, long ns, int C, int bins, float* out) {
+#pragma omp parallel for schedule(dynamic)
+    for (int c = 0; c < C; c++) {
+        float* work = (float*)malloc(sizeof(float) * (size_t)(6 * bins + 1));
+        cdf_channel_bins(t + (size_t)c * ldt, nt, s + (size_t)c * lds, ns, bins, out + (size_t)c * ldt, work);
+        free(work);
+    }
+}
+
 /* target [C, nt] (row stride ldt), source [C, ns] (row stride lds), out [C, nt] (row stride ldt).
  * dbg: NULL or [C, 2 + 4*256]. */
 void orc_cdf_match(const float* target, long ldt, long nt, const float* source, long lds, long ns, int C, float* out,

@@ -168,6 +168,17 @@ def cdf_match(target_cm, source_cm, debug=False):
 
 
 # ----------------------------------------------------------------------------------------------- sort mode
+def cdf_match_bins(target_cm, source_cm, bins):
+    """histmatch.py:49-69 with the reference's `bins` argument"""
+    t, s = _f32(target_cm), _f32(source_cm)
+    C, nt = t.shape
+    ns = s.shape[1]
+    out = np.empty_like(t)
+    lib().orc_cdf_match_bins(_p(t), ctypes.c_long(nt), ctypes.c_long(nt), _p(s), ctypes.c_long(ns), ctypes.c_long(ns),
+                             ctypes.c_int(C), ctypes.c_int(int(bins)), _p(out))
+    return out
+
+
 def sort_columns(keys_cm):
     k = _f32(keys_cm)
     C, n = k.shape

@@ -23,13 +23,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/optex.h but not exported by liboptex_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes and header disagree"
-    assert lib.optex_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.optex_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_size_helpers_need_no_gpu():
     lib = _lib.load()
     assert lib.optex_rotation_normals(256) == 256 * 257 // 2 - 1 == 32895
     assert lib.optex_cdf_ws_bytes(256, 4) > 4 * 256 * (4 * 4 + 2 * 256 * 4 + 3 * 256 * 4) - 1
+    assert lib.optex_cdf_bins_ws_bytes(256, 4, 256) > 0 and lib.optex_cdf_bins_ws_bytes(8, 2, 5000) == 6 * 4 * 5000 * 16
     assert lib.optex_ot_loop_ws_bytes(0, 16384, 12288, 256, 2, 1, 13, 0, 0) >= (2 * 16384 + 12288) * 256 * 4
 
 

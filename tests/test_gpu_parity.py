@@ -198,8 +198,39 @@ def test_cdf_match_public_api_golden(dev, golden):
                  g["deg_const_s_out"])
     assert biteq(ot.cdf_match(torch.full((1, 64), 3.0, device=dev), torch.full((1, 80), 3.0, device=dev)).cpu().numpy(),
                  g["deg_both_out"])
-    with pytest.raises(NotImplementedError):
-        ot.cdf_match(cu(g["target"], dev), cu(g["source"], dev), bins=128)
+    with pytest.raises(ValueError):
+        ot.cdf_match(cu(g["target"], dev), cu(g["source"], dev), bins=0)
+
+
+def test_cdf_match_other_bin_counts_golden(dev, golden):
+    """histmatch.py:49 with `bins` free (optex_cdf_match_bins): the reference's outputs for 11 bin counts, LDS- and
+    workspace-resident tables both"""
+    import optimaltextures_amd as ot
+    g = golden("cdf_match_bins.npz")
+    for b in g["bins"]:
+        out = ot.cdf_match(cu(g["target"], dev), cu(g["source"], dev), bins=int(b)).cpu().numpy()
+        assert biteq(out, g[f"out_{b}"]), int(b)
+    both = ot.cdf_match(torch.full((1, 64), 3.0, device=dev), torch.full((1, 80), 3.0, device=dev), bins=7)
+    assert biteq(both.cpu().numpy(), g["deg_both_out_7"])
+
+
+@pytest.mark.parametrize("bins", [5, 64, 256, 777, 4096])
+@pytest.mark.parametrize("S,Ss,C,nt,ns", [(1, 1, 16, 4096, 3000), (3, 1, 8, 1000, 1500), (2, 2, 5, 777, 640)])
+def test_cdf_match_bins_segments_vs_oracle_bit_exact(dev, bins, S, Ss, C, nt, ns):
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    rng = np.random.default_rng(S * 100 + C + bins)
+    t = (rng.standard_normal((S, C, nt)) * rng.uniform(0.5, 4, (S, C, 1)) + rng.uniform(-2, 2, (S, C, 1))).astype(np.float32)
+    s = relu_feat(rng, Ss, C, ns, scale=2.0, shift=0.5)
+    t[0, 0] = np.maximum(t[0, 0], 0)  # ties
+    # strided views: rows longer than the columns
+    tp = torch.zeros((S, C, nt + 12), device=dev)
+    tp[..., :nt] = cu(t, dev)
+    out = ops.cdf_match_bins_seg(Seg(tp, nt + 12, C * (nt + 12), nt, C, S), Seg.of(cu(s, dev)), bins).cpu().numpy()
+    for k in range(S):
+        assert biteq(out[k], orc.cdf_match_bins(t[k], s[k if Ss > 1 else 0], bins)), (k, bins)
+    if bins == 256:
+        assert biteq(out, ops.cdf_match_seg(Seg.of(cu(t, dev)), Seg.of(cu(s, dev))).cpu().numpy())
 
 
 @pytest.mark.parametrize("S,Ss,C,nt,ns", [(1, 1, 16, 4096, 3000), (3, 1, 8, 1000, 1500), (2, 2, 5, 777, 640),

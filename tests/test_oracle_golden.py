@@ -117,6 +117,16 @@ def test_cdf_match_degenerate_channels(golden):
     assert np.array_equal(c, g["deg_both_out"]) and np.all(c == 3.0)
 
 
+def test_cdf_match_other_bin_counts_bit_exact(golden):
+    """histmatch.py:49 `bins` free: the generalised restatement against the reference's outputs (gen_cdf_bins_golden.py)"""
+    g = golden("cdf_match_bins.npz")
+    for b in g["bins"]:
+        assert np.array_equal(orc.cdf_match_bins(g["target"], g["source"], int(b)), g[f"out_{b}"], equal_nan=True), int(b)
+    both = orc.cdf_match_bins(np.full((1, 64), 3.0, np.float32), np.full((1, 80), 3.0, np.float32), 7)
+    assert np.array_equal(both, g["deg_both_out_7"])
+    assert np.array_equal(orc.cdf_match_bins(g["target"], g["source"], 256), orc.cdf_match(g["target"], g["source"]))
+
+
 # ------------------------------------------------------------------------------------------------ A4/A5 linear modes
 LIN_TOL = 1e-4  # SURVEY 8c: single linear step <= 1e-4 * max|ref| (fp32 LAPACK vs fp64 factorization)
 
