@@ -33,6 +33,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     __shared__ float As[2][BK * BM];
     __shared__ float Bs[2][BPM ? BN * (BK + 1) : BK * BN];
 
+    if (a.live_until && a.live_idx >= *a.live_until) return;  // uniform for the launch
     const unsigned nblocks = gridDim.x;
     const unsigned L = xcd_remap(blockIdx.x, nblocks);
     const int tm_idx = L % a.tiles_m;

@@ -28,6 +28,9 @@ struct GemmArgs {
     // per (pixel tile, wave column):  rs_a / rs_b [n_seg][gemm_rowstat_parts][M]  (min / sum in rs_a, max in rs_b).
     // Saves the separate pass over the rotated map that col_minmax_kernel / col_mean_kernel would make.
     int rowstat; float* rs_a; float* rs_b;
+    // optional device-side switch of a launch that was enqueued before anyone knew whether it is needed (the later
+    // Newton-Schulz iterations of linalg.hip): the kernel returns at once if live_idx >= *live_until.  gemm_tn_kernel only.
+    const int* live_until = nullptr; int live_idx = 0;
 };
 
 // the launch of `a` (channel-major in and out) takes the hot-loop kernel, i.e. a.rowstat is honoured

@@ -345,7 +345,7 @@ constexpr int NS_MAX_ITERS = 64;
 // (A B)^T = B^T A^T, so At := B, Bm := A read "pixel-major" (element (k, i) at i * ld + k) and the result stored
 // pixel-major (transposed back).  OUT = alpha * alpha_seg[b] * (A B) + diag * I.  a_ss / b_ss: matrix strides (0 = shared).
 int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O, int C, int batch, float alpha,
-                  const float* alpha_seg, float diag, hipStream_t st) {
+                  const float* alpha_seg, float diag, const int* live_until, int live_idx, hipStream_t st) {
     const long cc = (long)C * C;
     GemmArgs a;
     a.At = B; a.lda = C; a.at_ss = b_ss;
@@ -356,15 +356,28 @@ int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O
     a.epi = 1; a.alpha = alpha; a.alpha_seg = alpha_seg; a.diag = diag; a.sym = 0;
     a.prof_cls = KC_SMALL_GEMM;
     a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
+    a.live_until = live_until; a.live_idx = live_idx;
     return gemm_tn_launch(a, OPTEX_PIXEL_MAJOR, OPTEX_PIXEL_MAJOR, st);
 }
 
-// Y0 = A / |A|_F, Z0 = I, and the per-matrix coefficients of all K iterations:
-//   cw[k][b] = a_k^2   (W = 1.5 I - 0.5 cw Z Y),   cy[k][b] = a_k (x sqrt|A|_F in the last iteration),
-//   cz[k][b] = a_k (/ sqrt|A|_F in the last iteration) — the scale of A comes back in the last epilogue.
+// lower end of the spectrum of Z0 Y0 = A / |A|_F; without a bound from the caller: fp32 cannot resolve eigenvalues below
+// ~2^-23 |A|_F anyway
+__device__ __forceinline__ double ns_l0(float lambda_min, double fro) {
+    double l2 = lambda_min > 0.f ? (double)lambda_min / fro : 0.0;
+    if (l2 < 1.2e-7) l2 = 1.2e-7;
+    if (l2 > 1.0) l2 = 1.0;
+    return sqrt(l2);
+}
+
+// Y0 = A / |A|_F, Z0 = I, |A|_F, and how many iterations this matrix needs: the recurrence l <- a l (3 - a^2 l^2) / 2 is a
+// guaranteed lower bound of the spectrum of Z Y, so once it is within fp32 round-off of 1 every eigenvalue is; one more
+// iteration polishes.  The launch-wide count (the largest need, made even so that the ping-pong ends in the same buffers
+// as the full count) is taken with an atomic: the host enqueues NS_ITERS iterations and the later ones switch themselves
+// off (GemmArgs::live_until) — no device-to-host round trip.
 __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ A, long a_ss, int C, int batch, int K,
-                                                      float lambda_min, float* __restrict__ Y, float* __restrict__ Z,
-                                                      float* __restrict__ cw, float* __restrict__ cy, float* __restrict__ cz) {
+                                                      int adaptive, float lambda_min, float* __restrict__ Y,
+                                                      float* __restrict__ Z, float* __restrict__ fro_out,
+                                                      int* __restrict__ k_need) {
     const int b = blockIdx.x;
     const float* Ab = A + (size_t)b * a_ss;
     const size_t cc = (size_t)C * C;
@@ -381,22 +394,17 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) {
         const double fro = sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
         fro_s = (float)fro;
-        // lower end of the spectrum of Z0 Y0 = A / |A|_F; without a bound from the caller: fp32 cannot resolve
-        // eigenvalues below ~2^-23 |A|_F anyway
-        double l2 = lambda_min > 0.f ? (double)lambda_min / fro : 0.0;
-        if (l2 < 1.2e-7) l2 = 1.2e-7;
-        if (l2 > 1.0) l2 = 1.0;
-        double l = sqrt(l2);
-        const double r = sqrt((double)fro_s);
-        for (int k = 0; k < K; k++) {
+        fro_out[b] = fro_s;
+        double l = ns_l0(lambda_min, fro);
+        int need = 0;
+        while (need < K && l < 1.0 - 6e-8) {
             const double a = sqrt(3.0 / (1.0 + l + l * l));
             l = a * l * (3.0 - a * a * l * l) * 0.5;
-            if (l > 1.0) l = 1.0;
-            const bool last = k == K - 1;
-            cw[(size_t)k * batch + b] = (float)(a * a);
-            cy[(size_t)k * batch + b] = (float)(last ? a * r : a);
-            cz[(size_t)k * batch + b] = (float)(last ? a / r : a);
+            need++;
         }
+        need += 1;
+        need += need & 1;
+        atomicMax(k_need, (adaptive && need < K) ? need : K);
     }
     __syncthreads();
     const float fro = fro_s;
@@ -408,15 +416,40 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
     }
 }
 
+// the per-matrix coefficients of the *k_need iterations that run:
+//   cw[k][b] = a_k^2   (W = 1.5 I - 0.5 cw Z Y),   cy[k][b] = a_k (x sqrt|A|_F in the last iteration),
+//   cz[k][b] = a_k (/ sqrt|A|_F in the last iteration) — the scale of A comes back in the last epilogue.
+__global__ __launch_bounds__(256) void ns_coef_kernel(const float* __restrict__ fro_in, int batch, float lambda_min,
+                                                      const int* __restrict__ k_need, float* __restrict__ cw,
+                                                      float* __restrict__ cy, float* __restrict__ cz) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int K = *k_need;
+    const double fro = (double)fro_in[b];
+    double l = ns_l0(lambda_min, fro);
+    const double r = sqrt(fro);
+    for (int k = 0; k < K; k++) {
+        const double a = sqrt(3.0 / (1.0 + l + l * l));
+        l = a * l * (3.0 - a * a * l * l) * 0.5;
+        if (l > 1.0) l = 1.0;
+        const bool last = k == K - 1;
+        cw[(size_t)k * batch + b] = (float)(a * a);
+        cy[(size_t)k * batch + b] = (float)(last ? a * r : a);
+        cz[(size_t)k * batch + b] = (float)(last ? a / r : a);
+    }
+}
+
 // 12 iterations of the interval-scaled iteration reach fp32 round-off for |A|_F / lambda_min <= 1e7 and further
-// iterations sit on the fixed point (tests/test_gpu_linalg.py), so the count is fixed
+// iterations sit on the fixed point (tests/test_gpu_linalg.py): the count that is ENQUEUED is fixed, the count that RUNS is
+// what the worst matrix of the launch needs (ns_init_kernel).  ns_adaptive = false runs all of them (tests, comparisons).
 constexpr int NS_ITERS = 12;
-static_assert(NS_ITERS <= NS_MAX_ITERS, "coefficient tables");
+static_assert(NS_ITERS <= NS_MAX_ITERS && NS_ITERS % 2 == 0, "coefficient tables; ping-pong parity");
+bool ns_adaptive = true;
 
 // Principal square root and inverse square root of `batch` symmetric positive definite C x C matrices whose spectrum
 // is bounded below by lambda_min (<= 0: unknown).  buf: ns_ws_floats(C, batch) floats (Y, Z, W, their ping-pong
 // partners and the coefficient tables).  The results land in *Yout / *Zout (pointers into buf).
-size_t ns_ws_floats(int C, int batch) { return (size_t)5 * batch * C * C + (size_t)3 * NS_MAX_ITERS * batch + 64; }
+size_t ns_ws_floats(int C, int batch) { return (size_t)5 * batch * C * C + (size_t)(3 * NS_MAX_ITERS + 1) * batch + 64; }
 
 int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float* buf, float** Yout, float** Zout, hipStream_t st) {
     const size_t cc = (size_t)C * C, sz = cc * batch;
@@ -429,17 +462,25 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float
     float* cw = buf + 5 * sz;
     float* cy = cw + (size_t)NS_MAX_ITERS * batch;
     float* cz = cy + (size_t)NS_MAX_ITERS * batch;
+    float* fro = cz + (size_t)NS_MAX_ITERS * batch;
+    int* k_need = reinterpret_cast<int*>(fro + batch);
+    if (hipMemsetAsync(k_need, 0, sizeof(int), st) != hipSuccess) {
+        set_error("ns_sqrt: cannot clear the iteration count");
+        return OPTEX_E_LAUNCH;
+    }
     {
         ProfScope prof(KC_NS_INIT, st, 0.0, 12.0 * (double)cc * batch);
-        hipLaunchKernelGGL(ns_init_kernel, dim3(batch), dim3(256), 0, st, A, a_ss, C, batch, K, lambda_min, Y, Z, cw, cy, cz);
+        hipLaunchKernelGGL(ns_init_kernel, dim3(batch), dim3(256), 0, st, A, a_ss, C, batch, K, ns_adaptive ? 1 : 0,
+                           lambda_min, Y, Z, fro, k_need);
+        hipLaunchKernelGGL(ns_coef_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, fro, batch, lambda_min, k_need, cw, cy, cz);
     }
     int rc = check_launch("ns_init_kernel");
     if (rc) return rc;
     for (int k = 0; k < K; k++) {
         const size_t o = (size_t)k * batch;
-        if ((rc = small_gemm_nn(Z, (long)cc, Y, (long)cc, W, C, batch, -0.5f, cw + o, 1.5f, st))) return rc;   // W = 1.5 I - 0.5 a^2 Z Y
-        if ((rc = small_gemm_nn(Y, (long)cc, W, (long)cc, Y2, C, batch, 1.f, cy + o, 0.f, st))) return rc;     // Y <- a Y W
-        if ((rc = small_gemm_nn(W, (long)cc, Z, (long)cc, Z2, C, batch, 1.f, cz + o, 0.f, st))) return rc;     // Z <- a W Z
+        if ((rc = small_gemm_nn(Z, (long)cc, Y, (long)cc, W, C, batch, -0.5f, cw + o, 1.5f, k_need, k, st))) return rc;   // W = 1.5 I - 0.5 a^2 Z Y
+        if ((rc = small_gemm_nn(Y, (long)cc, W, (long)cc, Y2, C, batch, 1.f, cy + o, 0.f, k_need, k, st))) return rc;     // Y <- a Y W
+        if ((rc = small_gemm_nn(W, (long)cc, Z, (long)cc, Z2, C, batch, 1.f, cz + o, 0.f, k_need, k, st))) return rc;     // Z <- a W Z
         float* t = Y; Y = Y2; Y2 = t;
         t = Z; Z = Z2; Z2 = t;
     }

@@ -19,7 +19,7 @@ namespace optex {
 int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, long b_ss, float* O, long ldo, long o_ss, int C,
                int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st, bool sym);
 int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O, int C, int batch, float alpha,
-                  const float* alpha_seg, float diag, hipStream_t st);
+                  const float* alpha_seg, float diag, const int* live_until, int live_idx, hipStream_t st);
 __global__ void rot_mean_kernel(const float* __restrict__ R, long r_ss, const float* __restrict__ mu, int mu_per_set, int C, int per,
                                 float* __restrict__ out);
 int chol_np(int C);
@@ -267,7 +267,7 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
             //   x = (R T)(y - mu_t) + R mu_sr,   R mu_sr = R R^T mu_s = mu_s,   (R T)^T = T^T R^T = At @ Rt
             // — the same product in another association (a C x C GEMM instead of a second C x n one); the content blend
             // rides in the epilogue as before.
-            if ((rc = small_gemm_nn(w.At, (long)cc, Rt, r_ss, w.M1, C, n_seg, 1.f, nullptr, 0.f, st))) return rc;
+            if ((rc = small_gemm_nn(w.At, (long)cc, Rt, r_ss, w.M1, C, n_seg, 1.f, nullptr, 0.f, nullptr, 0, st))) return rc;
             if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream)))
                 return rc;
         } else if (fused == 2) {

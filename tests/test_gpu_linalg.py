@@ -90,6 +90,37 @@ def test_spd_sqrt_ill_conditioned(dev, C, top, bound):
     assert np.abs(Y @ Z - np.eye(C)).max() <= max(1e-4, 4e-7 * np.sqrt(top) * 10)
 
 
+@pytest.mark.parametrize("C,top", [(64, 3.0), (256, 40.0), (256, 4e3), (181, 1e5)])
+def test_spd_sqrt_iteration_count_decided_on_device(dev, C, top):
+    """The Newton-Schulz iterations that run are what the worst matrix of the launch needs (ns_init_kernel; the later
+    launches switch themselves off): same square roots as the full count to fp32 round-off, for a batch that mixes a
+    well and a badly conditioned matrix.  `optex::ns_adaptive` is an internal switch of the library, not ABI."""
+    import ctypes
+    from optimaltextures_amd import _lib, ops
+    rng = np.random.default_rng(C)
+    q, _ = np.linalg.qr(rng.standard_normal((C, C)))
+    mats = []
+    for t in (top, 2.0):
+        w = np.concatenate([[1.0, 1.5], np.geomspace(2.0, t, C - 2)])
+        mats.append(((q * w) @ q.T).astype(np.float32))
+    A = cu(np.stack(mats), dev)
+    flag = ctypes.c_bool.in_dll(_lib.lib(), "_ZN5optex11ns_adaptiveE")
+    assert flag.value
+    Ya, Za = [x.clone() for x in ops.spd_sqrt(A, lambda_min=1.0)]
+    try:
+        flag.value = False
+        Yf, Zf = [x.clone() for x in ops.spd_sqrt(A, lambda_min=1.0)]
+    finally:
+        flag.value = True
+    tol = max(2e-6, 2e-7 * np.sqrt(top))
+    assert (Ya - Yf).abs().max().item() <= tol * Yf.abs().max().item()
+    assert (Za - Zf).abs().max().item() <= tol * Zf.abs().max().item()
+    for b, t in enumerate((top, 2.0)):
+        w = np.concatenate([[1.0, 1.5], np.geomspace(2.0, t, C - 2)])
+        ref = (q * np.sqrt(w)) @ q.T
+        assert np.abs(Ya[b].cpu().numpy().astype(np.float64) - ref).max() <= 1e-5 * max(1.0, np.sqrt(top) / 30) * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
 @pytest.mark.parametrize("C,S,Ss", [(8, 1, 1), (23, 3, 1), (64, 2, 2), (181, 2, 1), (256, 2, 1)])
 def test_transfer_operator_vs_oracle(dev, mode, C, S, Ss):
