@@ -541,7 +541,9 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
         if (a.M > 128 && huge >= 2LL * n_cu) return launch_cfg<256, 128, 16, 4, 2, BPM, OPM>(a, vec, st);
         return launch_cfg<128, 128, 16, 2, 2, BPM, OPM>(a, vec, st);
     }
-    // small problems: 64x64 tiles keep every CU busy
+    // small problems: 64x64 tiles keep every CU busy.  The C x C products of linalg.hip (64 x [256, 256] per launch) take
+    // 34 us each with 64x64, 64x128, 128x64 or 128x128 tiles alike (round 3 probe, 58-63 TFLOP/s): a launch is one round of
+    // resident blocks, bounded by its prologue / epilogue latency, not by the tile's arithmetic intensity.
     return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);
 }
 
