@@ -363,6 +363,19 @@ def main():
                     fused[mode] = round(B / (time.perf_counter() - t0), 3)
             result["textures_per_s_fused_rotations"] = fused.get(args.hist_mode)
             result["textures_per_s_fused_by_hist_mode"] = fused
+            # labelled too: the linear modes with the whole chain of a (pass, layer) collapsed into C x C algebra (SURVEY 7.4-3,
+            # fuse_rotations = 3): the statistics follow every step analytically, the feature map is read twice per call
+            collapsed = {}
+            with torch.inference_mode():
+                for mode in ("chol", "pca", "sym"):
+                    m = make_texturizer(mode, device, fuse_rotations=3)
+                    step(m)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    step(m)
+                    torch.cuda.synchronize()
+                    collapsed[mode] = round(B / (time.perf_counter() - t0), 3)
+            result["textures_per_s_collapsed_linear_chain"] = collapsed
         if "pcadefault" in args.other_modes.split(","):
             # the reference's default flags apart from the batch semantics: PCA ON (optex.py:109-110,119-120: C = k ~ 165-181
             # at relu3_1, ragged: the rotations take the R-stationary GEMM, project / unproject too), independent textures

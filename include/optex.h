@@ -185,6 +185,10 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
  *     GEMM per iteration instead of two;
  *   linear modes: the whole step as ONE affine map in un-rotated space, x' = M (x - mu_x) + mu_s with M = R T R^T and
  *     cov(x R) = R^T cov(x) R: one covariance + one feature-map GEMM per iteration instead of three.
+ * fuse_rotations = 3, optional fast path, never the default; linear modes, content must be NULL: the whole chain of
+ *   iterations in C x C algebra.  The covariance the next step needs follows analytically,
+ *   cov(x') = M cov(x) M^T, so the feature map is read once for its statistics and once by the single GEMM that applies
+ *   M_k ... M_1; agrees with the literal chain to accumulated fp32 round-off (tests/test_gpu_linalg.py).
  * ------------------------------------------------------------------------------------------------- */
 size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters,
                               int fuse_rotations, long r_seg_stride);

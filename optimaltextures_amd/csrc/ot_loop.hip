@@ -10,7 +10,8 @@
 // "style-feature statistics" the north star broadcasts between GPUs.  The pastiche side follows the reference step by
 // step — rotate, centre, covariance of the rotated map, transfer operator — with the C x C factorizations on the device
 // (linalg.hip); the last two products, `T @ hist_t` and `@ R^T`, are evaluated as one feature-map GEMM with the C x C
-// matrix R T (fuse_rotations = 2 keeps them apart, 1 is the labelled single-affine fast path).
+// matrix R T (fuse_rotations = 2 keeps them apart, 1 is the labelled single-affine fast path, 3 the labelled collapsed
+// chain: the statistics follow every step analytically and the feature map is touched twice per call).
 #include "gemm_args.h"
 
 using namespace optex;
@@ -65,6 +66,8 @@ struct LoopWs {
     float* ns_buf = nullptr;
     // fused (single-affine) linear path
     float *M1 = nullptr, *Mt = nullptr, *mu_x = nullptr;
+    // collapsed chain: covariance of the (virtual) current map and the accumulated operator, with their ping-pong partners
+    float *cov_x2 = nullptr, *acc = nullptr, *acc2 = nullptr;
     // per-tile row statistics of the rotated pastiche, written by the forward rotation GEMM's epilogue (GemmArgs::rowstat)
     float *rs_a = nullptr, *rs_b = nullptr;
     int rs_parts = 0;
@@ -106,6 +109,11 @@ struct LoopWs {
             M1 = b.take<float>((size_t)n_seg * cc);
             Mt = b.take<float>((size_t)n_seg * cc);
             mu_x = b.take<float>((size_t)n_seg * C);
+            if (fused == 3) {
+                cov_x2 = b.take<float>((size_t)n_seg * cc);
+                acc = b.take<float>((size_t)n_seg * cc);
+                acc2 = b.take<float>((size_t)n_seg * cc);
+            }
         }
         const int smax = n_seg > Ss ? n_seg : Ss;
         const long nmax = n > ns ? n : ns;
@@ -248,6 +256,44 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
     const long xs = (long)C * n;
     int rc;
     if ((rc = prepare_style(mode, w, style, ns, Ss, G, C, R32, r_ss, iters, st, stream))) return rc;
+    if (fused == 3) {
+        // The whole chain in C x C algebra (no content blend): every step is x' = M_i (x - mean) + mu_s with
+        // M_i = R_i T_i R_i^T, and the statistics the next step needs follow analytically,
+        //   cov(x') = M_i cov(x) M_i^T,   mean(x') = mu_s,
+        // so the feature map is read once for its statistics and once by the single GEMM that applies M_k ... M_1.
+        // small_gemm(L, B) = L^T @ B, small_gemm_nn(A, B) = A @ B.
+        float *cov = w.cov_t, *cov2 = w.cov_x2, *acc = w.acc, *acc2 = w.acc2;
+        if ((rc = optex_linear_stats(x, n, xs, n, C, n_seg, 0, 0.f, w.mu_x, cov, w.stats_ws, w.stats_ws_bytes, stream))) return rc;
+        for (int it = 0; it < iters; it++) {
+            const float* R = R32 + (size_t)it * cc;
+            const float* Rt = Rt32 + (size_t)it * cc;
+            if ((rc = small_gemm(cov, C, (long)cc, R, C, r_ss, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
+                return rc;                                                                   // cov(x) R
+            if ((rc = small_gemm(R, C, r_ss, w.M1, C, (long)cc, w.Mt, C, (long)cc, C, n_seg, true, 1.f, nullptr, kEps, st, true)))
+                return rc;                                                                   // R^T cov(x) R + eps I
+            if ((rc = transfer_operators(mode, w, w.Mt, C, n_seg, G, it, st))) return rc;   // At = T^T
+            if ((rc = small_gemm(w.At, C, (long)cc, Rt, C, r_ss, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
+                return rc;                                                                   // T R^T
+            if ((rc = small_gemm(w.M1, C, (long)cc, Rt, C, r_ss, w.Mt, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
+                return rc;                                                                   // R T^T R^T = M^T
+            if (it + 1 < iters) {
+                if ((rc = small_gemm(w.Mt, C, (long)cc, cov, C, (long)cc, w.M1, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false)))
+                    return rc;                                                               // M cov(x)
+                if ((rc = small_gemm_nn(w.M1, (long)cc, w.Mt, (long)cc, cov2, C, n_seg, 1.f, nullptr, 0.f, nullptr, 0, st)))
+                    return rc;                                                               // M cov(x) M^T
+                float* t = cov; cov = cov2; cov2 = t;
+            }
+            if (it == 0) {
+                if ((rc = copy_async(acc, w.Mt, (size_t)n_seg * cc, st))) return rc;
+            } else {
+                // (M_i ... M_1)^T = (M_{i-1} ... M_1)^T M_i^T
+                if ((rc = small_gemm_nn(acc, (long)cc, w.Mt, (long)cc, acc2, C, n_seg, 1.f, nullptr, 0.f, nullptr, 0, st))) return rc;
+                float* t = acc; acc = acc2; acc2 = t;
+            }
+        }
+        if ((rc = fgemm(acc, (long)cc, x, w.y2, C, n, n_seg, w.mu_x, w.mu_s, Ss > 1 ? C : 0, nullptr, 0.f, stream))) return rc;
+        return copy_async(x, w.y2, (size_t)n_seg * xs, st);
+    }
     float* cur = x;       // fused path: the affine map cannot run in place, x and y2 take turns
     float* nxt = w.y2;
     for (int it = 0; it < iters; it++) {
@@ -334,8 +380,12 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         return OPTEX_E_ARG;
     }
     const bool linear = mode >= MODE_CHOL;
-    if (fuse_rotations < 0 || fuse_rotations > 2) {
-        set_error("optex_ot_loop: fuse_rotations = %d (0, 1 or 2)", fuse_rotations);
+    if (fuse_rotations < 0 || fuse_rotations > 3) {
+        set_error("optex_ot_loop: fuse_rotations = %d (0, 1, 2 or 3)", fuse_rotations);
+        return OPTEX_E_ARG;
+    }
+    if (fuse_rotations == 3 && (!linear || content)) {
+        set_error("optex_ot_loop: fuse_rotations = 3 (collapsed chain) is for the linear modes without a content blend");
         return OPTEX_E_ARG;
     }
     if (!linear && fuse_rotations == 2) fuse_rotations = 0;

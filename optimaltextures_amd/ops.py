@@ -221,7 +221,10 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
     updated IN PLACE.  R32 / Rt32: [iters, C, C] shared by all segments (the reference shares R across its batch), or
     [S, iters, C, C]: one rotation set per segment.  fuse_rotations = True / 1 (labelled fast paths, fp32
     round-off differences only): cdf / sort evaluate (m @ R_i^T) @ R_{i+1} as m @ (R_i^T R_{i+1}) (needs content=None);
-    the linear modes run the whole step as one affine map in un-rotated space."""
+    the linear modes run the whole step as one affine map in un-rotated space.  fuse_rotations = 3 (labelled
+    too): the linear modes without a content blend run the whole CHAIN in C x C algebra — cov(x') = M cov(x) M^T follows every
+    step analytically — and touch the feature map twice per call; with a content blend, or for cdf / sort, 3
+    means 1."""
     lib = _lib.lib()
     S, C, n = x.shape
     Ss, Cs, ns = style.shape
@@ -235,7 +238,11 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
         assert content.shape == x.shape and content.is_contiguous()
     m = LOOP_MODES[mode]
     # 0 = default, 1 / True = labelled fast path, 2 = linear modes with the apply and the rotation back as separate GEMMs
-    fuse = int(fuse_rotations) if (content is None or m >= 2) else (0 if int(fuse_rotations) == 1 else int(fuse_rotations))
+    fuse = int(fuse_rotations)
+    if fuse == 3 and (content is not None or m < 2):
+        fuse = 1
+    if content is not None and m < 2 and fuse == 1:
+        fuse = 0
     ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse, r_ss), x.device)
     check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), r_ss, iters,
                             ptr(content), ctypes.c_float(strength), fuse, ptr(ws), ws.numel(), stream_ptr()))

@@ -167,7 +167,9 @@ def test_ot_loop_linear_modes_vs_oracle_chain(dev, mode, S, Ss, C, n, ns, blend)
                 w = orc.content_blend(w, content[s], 0.05)
         want[s] = w
     outs = {}
-    for fused in (0, 1, 2):  # default (apply + rotation back as one GEMM), single-affine fast path, literal three GEMMs
+    # default (apply + rotation back as one GEMM), single-affine fast path, literal three GEMMs, collapsed chain (SURVEY
+    # 7.4-3: statistics propagated analytically, one feature-map GEMM per call; with a content blend 3 runs as 1)
+    for fused in (0, 1, 2, 3):
         xd = cu(x, dev)
         ops.ot_loop(mode, xd, cu(sty, dev), cu(R, dev), cu(Rt, dev), content=cu(content, dev) if blend else None,
                     strength=0.05 if blend else 0.0, fuse_rotations=fused)
@@ -177,6 +179,32 @@ def test_ot_loop_linear_modes_vs_oracle_chain(dev, mode, S, Ss, C, n, ns, blend)
         assert err <= 3 * LIN_TOL, f"fused={fused}"
     assert np.abs(outs[1] - outs[0]).max() <= 5e-5 * np.abs(want).max()
     assert np.abs(outs[2] - outs[0]).max() <= 2e-5 * np.abs(want).max()
+    assert np.abs(outs[3] - outs[0]).max() <= 1e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
+def test_collapsed_chain_at_bench_shape(dev, mode):
+    """fuse_rotations = 3 at the bench's own shape (8 textures of [256, 16384] against a [256, 12288] style, 13 iterations —
+    the longest chain of the default schedule): the collapsed chain stays within 2e-4 of the literal loop's result"""
+    from optimaltextures_amd import ops, rotation
+    rng = np.random.default_rng(77)
+    S, C, n, ns, iters = 8, 256, 16384, 12288, 13
+    mix = (rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)   # correlated channels, like VGG features
+    x = np.maximum(np.einsum("ck,skn->scn", mix, rng.standard_normal((S, C, n)).astype(np.float32)) * 3 + 0.4, 0).astype(np.float32)
+    sty = np.maximum(np.einsum("ck,skn->scn", mix, rng.standard_normal((1, C, ns)).astype(np.float32)) * 5 + 0.2, 0).astype(np.float32)
+    R, Rt = rotation.rotations(C, iters, dev, rng=np.random.RandomState(3))
+    outs = {}
+    for fused in (0, 3):
+        xd = cu(x, dev)
+        ops.ot_loop(mode, xd, cu(sty, dev), R, Rt, fuse_rotations=fused)
+        outs[fused] = xd
+    scale = outs[0].abs().max().item()
+    err = (outs[3] - outs[0]).abs().max().item() / scale
+    print(f"{mode}: collapsed vs literal, 13 iterations at [8, 256, 16384]: {err:.2e} of max |x| = {scale:.2f}")
+    assert err <= 2e-4
+    # and the chain did something: the result carries the style's statistics
+    mu = outs[3].mean(dim=2)
+    assert (mu - cu(sty, dev)[0].mean(dim=1)[None]).abs().max().item() <= 1e-3 * scale
 
 
 @pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
@@ -190,7 +218,7 @@ def test_ot_loop_linear_chain13_reference_golden(dev, golden, mode):
     Rt = np.ascontiguousarray(R.transpose(0, 2, 1))
     x = np.ascontiguousarray(past.reshape(-1, C).T)[None]
     s = np.ascontiguousarray(sty.reshape(-1, C).T)[None]
-    for fused in (0, 1, 2):
+    for fused in (0, 1, 2, 3):
         xd = cu(x, dev)
         ops.ot_loop(mode, xd, cu(s, dev), cu(R, dev), cu(Rt, dev), fuse_rotations=fused)
         got = xd.cpu().numpy()[0].T.reshape(past.shape)
@@ -224,7 +252,7 @@ def test_driver_linear_modes_use_the_fused_loop(dev):
 
 @pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
 @pytest.mark.parametrize("S,C,n,ns,blend,fused", [(3, 32, 1024, 768, False, 0), (2, 23, 400, 300, True, 2), (4, 181, 4096, 3072, False, 0),
-                                                   (2, 64, 2048, 1500, True, 1)])
+                                                   (2, 64, 2048, 1500, True, 1), (3, 96, 2048, 1500, False, 3)])
 def test_linear_modes_per_texture_rotation_streams(dev, mode, S, C, n, ns, blend, fused):
     """un-shared rotations in the linear modes (optex.py:168 run once per image): texture i of a batch driven by one numpy
     stream per texture equals the B = 1 run with stream i (to round-off: the split-K partition of the covariance depends on
