@@ -279,15 +279,134 @@ __global__ __launch_bounds__(256) void gram128_kernel(const float* __restrict__ 
             }
 }
 
+// The whole upper triangle of one segment's Gram matrix per workgroup (192 < C <= 256, round 3).  The 8 x 8 grid of 32 x 32
+// MFMA tiles has 36 tiles on or above the diagonal: nine per wave, grouped so that a wave reads five to seven 32-channel
+// fragments per k-step for its nine MFMAs (row blocks A = {0,1,2}, B = {3,4,5}, C = {6,7}: wave 0 takes A x B, wave 1 the
+// triangles of A and C, wave 2 A x C and three tiles of B x C, wave 3 the triangle of B and the rest of B x C).  Against
+// the 128 x 128 tile pairs of gram128_kernel: no idle wave on diagonal tiles (36 tile products per pixel pair instead of
+// 48 issue slots for 40), and every pixel chunk is staged once per segment instead of once per tile pair (256 rows
+// instead of 512).  grid = (splits, n_seg); part[seg][split][C][C] receives the upper 32 x 32 tiles.
+constexpr int TRI_K = 32, TRI_STR = TRI_K + 1, TRI_ROWS = 256;
+constexpr size_t TRI_LDS = (size_t)2 * TRI_ROWS * TRI_STR * sizeof(float);
+__device__ constexpr unsigned char TRI_I[4][9] = {{0, 0, 0, 1, 1, 1, 2, 2, 2}, {0, 0, 0, 1, 1, 2, 6, 6, 7},
+                                                  {0, 0, 1, 1, 2, 2, 3, 3, 4}, {3, 3, 3, 4, 4, 5, 4, 5, 5}};
+__device__ constexpr unsigned char TRI_J[4][9] = {{3, 4, 5, 3, 4, 5, 3, 4, 5}, {0, 1, 2, 1, 2, 2, 6, 7, 7},
+                                                  {6, 7, 6, 7, 6, 7, 6, 7, 6}, {3, 4, 5, 4, 5, 5, 7, 6, 7}};
+
+template <int W>
+__device__ __forceinline__ void tri_chunk(const float* __restrict__ X, int l31, int h, floatx16 (&acc)[9]) {
+    constexpr unsigned need = [] {
+        unsigned m = 0;
+        for (int t = 0; t < 9; t++) m |= (1u << TRI_I[W][t]) | (1u << TRI_J[W][t]);
+        return m;
+    }();
+#pragma unroll 2
+    for (int j = 0; j < TRI_K / 2; j++) {
+        float f[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+            if (need >> b & 1) f[b] = X[(b * 32 + l31) * TRI_STR + 2 * j + h];
+        // (channels past C are staged as zeros: for 192 < C <= 224 the tiles of block 7 multiply zeros — no branch in here)
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[TRI_I[W][t]], f[TRI_J[W][t]], acc[t], 0, 0, 0);
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void tri_store(float* __restrict__ o, int C, int l31, int h, const floatx16 (&acc)[9]) {
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = TRI_I[W][t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int j = TRI_J[W][t] * 32 + l31;
+            if (i < C && j < C) o[(size_t)i * C + j] = acc[t][r];
+        }
+}
+
+// the whole kernel body of wave W: every wave runs its own copy of the chunk loop (the same number of barriers in each), so
+// that its nine accumulators stay in one place for the whole launch — with the wave switch inside the loop the compiler
+// moved all 144 accumulator registers in and out of the branch once per chunk
+template <int W>
+__device__ __forceinline__ void tri_main(const float* __restrict__ xs, long ld, long n, int C, const float* __restrict__ mus,
+                                         long p_beg, long p_end, float* __restrict__ o, float* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    // a thread stages the same 8 rows (tid / 8 + 32 q) of every chunk, 4 pixels each: one unconditional float4 per row
+    // (clamped address, zeroed by selects past the end of this block's pixel range or of the channels)
+    constexpr int NQ = TRI_ROWS * TRI_K / 4 / 256;
+    const int row0 = tid >> 3, px = (tid & 7) * 4;
+    float m[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) m[q] = mus[row0 + 32 * q < C ? row0 + 32 * q : 0];
+    const float* base = xs + (size_t)row0 * ld + px;
+    const long qstride = 32 * ld;
+    float4 rv[NQ];
+    auto load_global = [&](long p0) {
+        const long pc = (p0 + px < n) ? p0 : 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) rv[q] = *reinterpret_cast<const float4*>(base + (row0 + 32 * q < C ? q * qstride : 0) + pc);
+    };
+    auto store_lds = [&](int buf, long p0) {
+        const long left = p_end - (p0 + px);  // pixels of this thread's quad inside the block's range
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            // (rows past C hold a copy of a real row: they only reach Gram entries that are never stored)
+            float* d = &smem[buf * TRI_ROWS * TRI_STR + (row0 + 32 * q) * TRI_STR + px];
+            d[0] = left > 0 ? rv[q].x - m[q] : 0.f;
+            d[1] = left > 1 ? rv[q].y - m[q] : 0.f;
+            d[2] = left > 2 ? rv[q].z - m[q] : 0.f;
+            d[3] = left > 3 ? rv[q].w - m[q] : 0.f;
+        }
+    };
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    const long nchunks = (p_end - p_beg + TRI_K - 1) / TRI_K;
+    if (nchunks > 0) {
+        load_global(p_beg);
+        store_lds(0, p_beg);
+    }
+    __syncthreads();
+    for (long kc = 0; kc < nchunks; kc++) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_global(p_beg + (kc + 1) * TRI_K);
+        tri_chunk<W>(&smem[buf * TRI_ROWS * TRI_STR], l31, h, acc);
+        if (kc + 1 < nchunks) store_lds(buf ^ 1, p_beg + (kc + 1) * TRI_K);
+        __syncthreads();
+    }
+    tri_store<W>(o, C, l31, h, acc);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_tri_kernel(
+    const float* __restrict__ x, long ld, long seg_stride, long n, int C, const float* __restrict__ mu, long chunk,
+    float* __restrict__ part) {
+    extern __shared__ __align__(16) float g_smem[];  // [2][TRI_ROWS * TRI_STR]
+    const int seg = blockIdx.y, split = blockIdx.x;
+    const float* xs = x + (size_t)seg * seg_stride;
+    const float* mus = mu + (size_t)seg * C;
+    const long p_beg = (long)split * chunk, p_end = (p_beg + chunk < n) ? p_beg + chunk : n;
+    float* o = part + ((size_t)seg * gridDim.x + split) * C * C;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) tri_main<0>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+    else if (wave == 1) tri_main<1>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+    else if (wave == 2) tri_main<2>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+    else tri_main<3>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+}
+
 // cov[s][i][j] = sum_split part / N + eps * (i == j); lower triangle mirrored from the upper tiles.
 // pool: one covariance over all segments (the reference's batch semantics), N = n * n_seg.
 __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n_seg, int splits, int pool, float N,
-                                    float eps, float* __restrict__ cov) {
+                                    float eps, int gt, float* __restrict__ cov) {
     const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.z;
     if (j >= C) return;
-    // element (i, j) lives in the 64 x 64 block (i/64, j/64) if that is an upper block, else read (j, i).  Both Gram kernels
-    // leave exactly the upper 64-blocks behind (the 128-tile kernel skips the block below the diagonal of a diagonal tile).
-    const bool upper = (i / GT) <= (j / GT);
+    // element (i, j) lives in the gt x gt block (i/gt, j/gt) if that is an upper block, else read (j, i).  The tile-pair
+    // kernels leave exactly the upper 64-blocks behind (the 128-tile kernel skips the block below the diagonal of a diagonal
+    // tile), the whole-triangle kernel the upper 32-blocks.
+    const bool upper = (i / gt) <= (j / gt);
     const int ri = upper ? i : j, rj = upper ? j : i;
     float sum = 0.f;
     const int s_beg = pool ? 0 : s, s_end = pool ? n_seg : s + 1;
@@ -299,6 +418,7 @@ __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n
 }
 
 int device_cu_count();
+bool gram_tri_enabled = true;  // (internal, not ABI: tests compare the whole-triangle kernel with the tile-pair kernel)
 
 static int gram_splits(long n, int C, int n_seg, bool big) {
     // 64-tiles: two blocks' worth of work per CU; 128-tiles (two resident blocks per CU, long blocks): about four rounds of
@@ -351,9 +471,17 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
     int rc = check_launch("col_mean_kernel");
     if (rc) return rc;
     const bool big = C > GT && vec && n % 4 == 0;  // the 128-tile kernel loads unconditional float4s
+    const bool tri = big && C > 192 && C <= TRI_ROWS && gram_tri_enabled;
     const int gt = big ? GT2 : GT;
     const int tiles = (C + gt - 1) / gt, pairs = tiles * (tiles + 1) / 2;
-    const int splits = gram_splits(n, C, n_seg, big);
+    int splits = gram_splits(n, C, n_seg, big);
+    if (tri) {
+        // one workgroup per (split, segment), two resident per CU: whole rounds of resident workgroups
+        const long target = 2L * device_cu_count();
+        long want = (target + n_seg - 1) / n_seg, maxs = (n + 255) / 256;
+        want = want > maxs ? maxs : want;
+        splits = (int)(want > G_MAX_SPLITS ? G_MAX_SPLITS : (want < 1 ? 1 : want));
+    }
     long chunk = (n + splits - 1) / splits;
     chunk = (chunk + GK - 1) / GK * GK;  // chunk starts stay multiples of 4 pixels (float4 loads)
     float* part = static_cast<float*>(ws);
@@ -362,7 +490,21 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
         // algorithmic flops = the upper-triangular 64 x 64 blocks: b (b + 1) / 2 * 64 * 64 * 2n per segment
         const int b64 = (C + GT - 1) / GT;
         ProfScope prof(KC_GRAM, st, 2.0 * (b64 * (b64 + 1) / 2) * GT * GT * (double)n * n_seg, 4.0 * (double)n * C * n_seg);
-        if (big) {
+        if (tri) {
+            static bool tri_attr[64] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (!tri_attr[dev & 63]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tri_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS);
+                if (e != hipSuccess) {
+                    set_error("gram_tri_kernel: cannot reserve LDS: %s", hipGetErrorString(e));
+                    return OPTEX_E_LAUNCH;
+                }
+                tri_attr[dev & 63] = true;
+            }
+            hipLaunchKernelGGL(gram_tri_kernel, dim3(splits, n_seg), dim3(256), TRI_LDS, st, x, ld, seg_stride, n, C, mu, chunk, part);
+        } else if (big) {
             constexpr int gk = 32;
             const size_t lds = (size_t)4 * GT2 * (gk + 1) * sizeof(float);
             auto kern = gram128_kernel<gk>;
@@ -389,6 +531,6 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
     const float N = pool ? (float)((double)n * n_seg) : (float)n;
     ProfScope prof(KC_COVFIN, st, 0.0, 4.0 * (double)C * C * n_seg * (splits + 1));
     hipLaunchKernelGGL(cov_finalize_kernel, dim3((C + 255) / 256, C, pool ? 1 : n_seg), dim3(256), 0, st, part, C, n_seg,
-                       splits, pool, N, eps, cov);
+                       splits, pool, N, eps, tri ? 32 : GT, cov);
     return check_launch("cov_finalize_kernel");
 }

@@ -525,6 +525,43 @@ def test_linear_stats_vs_fp64(dev, S, C, n, pool):
     assert np.array_equal(cov, np.swapaxes(cov, -1, -2))  # exactly symmetric (mirrored tiles)
 
 
+@pytest.mark.parametrize("S,C,n,pool", [(3, 256, 4096, False), (2, 256, 16384, True), (2, 200, 1000, False), (1, 224, 6400, False),
+                                         (5, 193, 260, False), (1, 256, 36, False)])
+def test_linear_stats_whole_triangle_kernel(dev, S, C, n, pool):
+    """192 < C <= 256: one workgroup computes the 36 upper 32 x 32 tiles of a segment's Gram matrix (gram_tri_kernel).
+    Against numpy fp64, and against the tile-pair kernel it replaces (`optex::gram_tri_enabled`, an internal switch of the
+    library, not ABI) — different split-K partitions, so equal to round-off, not bit for bit."""
+    import ctypes
+    from optimaltextures_amd import _lib, ops
+    from optimaltextures_amd.ops import Seg
+    rng = np.random.default_rng(C + n)
+    x = relu_feat(rng, S, C, n, scale=2.0, shift=0.4)
+    flag = ctypes.c_bool.in_dll(_lib.lib(), "_ZN5optex16gram_tri_enabledE")
+    assert flag.value
+    ops.profile_collect()
+    ops.profile_enable(True)
+    mu, cov = ops.linear_stats(Seg.of(cu(x, dev)), pool=pool, eps=1.0)
+    ops.profile_enable(False)
+    assert ops.profile_collect()["gram"]["launches"] == 1
+    try:
+        flag.value = False
+        mu2, cov2 = ops.linear_stats(Seg.of(cu(x, dev)), pool=pool, eps=1.0)
+    finally:
+        flag.value = True
+    assert torch.equal(mu, mu2)
+    assert (cov - cov2).abs().max().item() <= 2e-6 * cov2.abs().max().item()
+    cov = cov.cpu().numpy()
+    h = x.astype(np.float64)
+    h = h - h.mean(-1, keepdims=True)
+    if pool:
+        hp = np.concatenate(list(h), axis=1)
+        ref = hp @ hp.T / hp.shape[1] + np.eye(C)
+    else:
+        ref = np.einsum("sin,sjn->sij", h, h) / n + np.eye(C)
+    assert maxrel(cov, ref) < 5e-6
+    assert np.array_equal(cov, np.swapaxes(cov, -1, -2))
+
+
 # ================================================================================================ A5 hist_match
 @pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
 def test_hist_match_linear_golden(dev, golden, mode):
