@@ -549,7 +549,7 @@ def test_linear_stats_whole_triangle_kernel(dev, S, C, n, pool):
     finally:
         flag.value = True
     assert torch.equal(mu, mu2)
-    assert (cov - cov2).abs().max().item() <= 2e-6 * cov2.abs().max().item()
+    assert (cov - cov2).abs().max().item() <= 1e-5 * cov2.abs().max().item()
     cov = cov.cpu().numpy()
     h = x.astype(np.float64)
     h = h - h.mean(-1, keepdims=True)
