@@ -279,62 +279,70 @@ __global__ __launch_bounds__(256) void gram128_kernel(const float* __restrict__ 
             }
 }
 
-// The whole upper triangle of one segment's Gram matrix per workgroup (192 < C <= 256, round 3).  The 8 x 8 grid of 32 x 32
-// MFMA tiles has 36 tiles on or above the diagonal: nine per wave, grouped so that a wave reads five to seven 32-channel
-// fragments per k-step for its nine MFMAs (row blocks A = {0,1,2}, B = {3,4,5}, C = {6,7}: wave 0 takes A x B, wave 1 the
-// triangles of A and C, wave 2 A x C and three tiles of B x C, wave 3 the triangle of B and the rest of B x C).  Against
-// the 128 x 128 tile pairs of gram128_kernel: no idle wave on diagonal tiles (36 tile products per pixel pair instead of
-// 48 issue slots for 40), and every pixel chunk is staged once per segment instead of once per tile pair (256 rows
-// instead of 512).  grid = (splits, n_seg); part[seg][split][C][C] receives the upper 32 x 32 tiles.
-constexpr int TRI_K = 32, TRI_STR = TRI_K + 1, TRI_ROWS = 256;
-constexpr size_t TRI_LDS = (size_t)2 * TRI_ROWS * TRI_STR * sizeof(float);
-__device__ constexpr unsigned char TRI_I[4][9] = {{0, 0, 0, 1, 1, 1, 2, 2, 2}, {0, 0, 0, 1, 1, 2, 6, 6, 7},
-                                                  {0, 0, 1, 1, 2, 2, 3, 3, 4}, {3, 3, 3, 4, 4, 5, 4, 5, 5}};
-__device__ constexpr unsigned char TRI_J[4][9] = {{3, 4, 5, 3, 4, 5, 3, 4, 5}, {0, 1, 2, 1, 2, 2, 6, 7, 7},
-                                                  {6, 7, 6, 7, 6, 7, 6, 7, 6}, {3, 4, 5, 4, 5, 5, 7, 6, 7}};
+// The whole upper triangle of one segment's Gram matrix per workgroup (128 < C <= 256, round 3).  NB = 8 (192 < C): the
+// 8 x 8 grid of 32 x 32 MFMA tiles has 36 tiles on or above the diagonal, nine per wave, grouped so that a wave reads five
+// to seven 32-channel fragments per k-step for its nine MFMAs (row blocks A = {0,1,2}, B = {3,4,5}, C = {6,7}: wave 0
+// takes A x B, wave 1 the triangles of A and C, wave 2 A x C and three tiles of B x C, wave 3 the triangle of B and the
+// rest of B x C).  NB = 6 (C <= 192, the PCA ranks of relu3_1): 21 tiles as 6 + 6 + 5 + 4.  Against the 128 x 128 tile
+// pairs of gram128_kernel: no idle wave on diagonal tiles (36 tile products per pixel pair instead of 48 issue slots for
+// 40), and every pixel chunk is staged once per segment instead of once per tile pair (256 rows instead of 512).
+// grid = (splits, n_seg); part[seg][split][C][C] receives the upper 32 x 32 tiles.
+constexpr int TRI_K = 32, TRI_STR = TRI_K + 1;
+constexpr size_t tri_lds_bytes(int NB) { return (size_t)2 * NB * 32 * TRI_STR * sizeof(float); }
+__device__ constexpr unsigned char TRI8_I[4][9] = {{0, 0, 0, 1, 1, 1, 2, 2, 2}, {0, 0, 0, 1, 1, 2, 6, 6, 7},
+                                                   {0, 0, 1, 1, 2, 2, 3, 3, 4}, {3, 3, 3, 4, 4, 5, 4, 5, 5}};
+__device__ constexpr unsigned char TRI8_J[4][9] = {{3, 4, 5, 3, 4, 5, 3, 4, 5}, {0, 1, 2, 1, 2, 2, 6, 7, 7},
+                                                   {6, 7, 6, 7, 6, 7, 6, 7, 6}, {3, 4, 5, 4, 5, 5, 7, 6, 7}};
+__device__ constexpr unsigned char TRI6_I[4][6] = {{0, 0, 0, 1, 1, 2}, {3, 3, 3, 4, 4, 5}, {0, 0, 0, 1, 1, 0}, {1, 2, 2, 2, 0, 0}};
+__device__ constexpr unsigned char TRI6_J[4][6] = {{0, 1, 2, 1, 2, 2}, {3, 4, 5, 4, 5, 5}, {3, 4, 5, 3, 4, 0}, {5, 3, 4, 5, 0, 0}};
+template <int NB, int W> constexpr int tri_cnt() { return NB == 8 ? 9 : (W < 2 ? 6 : (W == 2 ? 5 : 4)); }
+template <int NB, int W> constexpr int tri_i(int t) { return NB == 8 ? TRI8_I[W][t] : TRI6_I[W][t]; }
+template <int NB, int W> constexpr int tri_j(int t) { return NB == 8 ? TRI8_J[W][t] : TRI6_J[W][t]; }
 
-template <int W>
-__device__ __forceinline__ void tri_chunk(const float* __restrict__ X, int l31, int h, floatx16 (&acc)[9]) {
+template <int NB, int W>
+__device__ __forceinline__ void tri_chunk(const float* __restrict__ X, int l31, int h, floatx16 (&acc)[tri_cnt<NB, W>()]) {
+    constexpr int CNT = tri_cnt<NB, W>();
     constexpr unsigned need = [] {
         unsigned m = 0;
-        for (int t = 0; t < 9; t++) m |= (1u << TRI_I[W][t]) | (1u << TRI_J[W][t]);
+        for (int t = 0; t < CNT; t++) m |= (1u << tri_i<NB, W>(t)) | (1u << tri_j<NB, W>(t));
         return m;
     }();
 #pragma unroll 2
     for (int j = 0; j < TRI_K / 2; j++) {
-        float f[8];
+        float f[NB];
 #pragma unroll
-        for (int b = 0; b < 8; b++)
+        for (int b = 0; b < NB; b++)
             if (need >> b & 1) f[b] = X[(b * 32 + l31) * TRI_STR + 2 * j + h];
-        // (channels past C are staged as zeros: for 192 < C <= 224 the tiles of block 7 multiply zeros — no branch in here)
+        // (channels past C hold a copy of a real row: their tiles only reach Gram entries that are never stored — no branch)
 #pragma unroll
-        for (int t = 0; t < 9; t++)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[TRI_I[W][t]], f[TRI_J[W][t]], acc[t], 0, 0, 0);
+        for (int t = 0; t < CNT; t++)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[tri_i<NB, W>(t)], f[tri_j<NB, W>(t)], acc[t], 0, 0, 0);
     }
 }
 
-template <int W>
-__device__ __forceinline__ void tri_store(float* __restrict__ o, int C, int l31, int h, const floatx16 (&acc)[9]) {
+template <int NB, int W>
+__device__ __forceinline__ void tri_store(float* __restrict__ o, int C, int l31, int h, const floatx16 (&acc)[tri_cnt<NB, W>()]) {
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int t = 0; t < tri_cnt<NB, W>(); t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int i = TRI_I[W][t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int j = TRI_J[W][t] * 32 + l31;
+            const int i = tri_i<NB, W>(t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int j = tri_j<NB, W>(t) * 32 + l31;
             if (i < C && j < C) o[(size_t)i * C + j] = acc[t][r];
         }
 }
 
 // the whole kernel body of wave W: every wave runs its own copy of the chunk loop (the same number of barriers in each), so
-// that its nine accumulators stay in one place for the whole launch — with the wave switch inside the loop the compiler
+// that its accumulators stay in one place for the whole launch — with the wave switch inside the loop the compiler
 // moved all 144 accumulator registers in and out of the branch once per chunk
-template <int W>
+template <int NB, int W>
 __device__ __forceinline__ void tri_main(const float* __restrict__ xs, long ld, long n, int C, const float* __restrict__ mus,
                                          long p_beg, long p_end, float* __restrict__ o, float* smem) {
+    constexpr int ROWS = NB * 32, CNT = tri_cnt<NB, W>();
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    // a thread stages the same 8 rows (tid / 8 + 32 q) of every chunk, 4 pixels each: one unconditional float4 per row
-    // (clamped address, zeroed by selects past the end of this block's pixel range or of the channels)
-    constexpr int NQ = TRI_ROWS * TRI_K / 4 / 256;
+    // a thread stages the same NQ rows (tid / 8 + 32 q) of every chunk, 4 pixels each: one unconditional float4 per row
+    // (clamped address, zeroed by selects past the end of this block's pixel range)
+    constexpr int NQ = ROWS * TRI_K / 4 / 256;
     const int row0 = tid >> 3, px = (tid & 7) * 4;
     float m[NQ];
 #pragma unroll
@@ -351,17 +359,16 @@ __device__ __forceinline__ void tri_main(const float* __restrict__ xs, long ld, 
         const long left = p_end - (p0 + px);  // pixels of this thread's quad inside the block's range
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            // (rows past C hold a copy of a real row: they only reach Gram entries that are never stored)
-            float* d = &smem[buf * TRI_ROWS * TRI_STR + (row0 + 32 * q) * TRI_STR + px];
+            float* d = &smem[buf * ROWS * TRI_STR + (row0 + 32 * q) * TRI_STR + px];
             d[0] = left > 0 ? rv[q].x - m[q] : 0.f;
             d[1] = left > 1 ? rv[q].y - m[q] : 0.f;
             d[2] = left > 2 ? rv[q].z - m[q] : 0.f;
             d[3] = left > 3 ? rv[q].w - m[q] : 0.f;
         }
     };
-    floatx16 acc[9];
+    floatx16 acc[CNT];
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int t = 0; t < CNT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
@@ -374,27 +381,28 @@ __device__ __forceinline__ void tri_main(const float* __restrict__ xs, long ld, 
     for (long kc = 0; kc < nchunks; kc++) {
         const int buf = kc & 1;
         if (kc + 1 < nchunks) load_global(p_beg + (kc + 1) * TRI_K);
-        tri_chunk<W>(&smem[buf * TRI_ROWS * TRI_STR], l31, h, acc);
+        tri_chunk<NB, W>(&smem[buf * ROWS * TRI_STR], l31, h, acc);
         if (kc + 1 < nchunks) store_lds(buf ^ 1, p_beg + (kc + 1) * TRI_K);
         __syncthreads();
     }
-    tri_store<W>(o, C, l31, h, acc);
+    tri_store<NB, W>(o, C, l31, h, acc);
 }
 
+template <int NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_tri_kernel(
     const float* __restrict__ x, long ld, long seg_stride, long n, int C, const float* __restrict__ mu, long chunk,
     float* __restrict__ part) {
-    extern __shared__ __align__(16) float g_smem[];  // [2][TRI_ROWS * TRI_STR]
+    extern __shared__ __align__(16) float g_smem[];  // [2][NB * 32 * TRI_STR]
     const int seg = blockIdx.y, split = blockIdx.x;
     const float* xs = x + (size_t)seg * seg_stride;
     const float* mus = mu + (size_t)seg * C;
     const long p_beg = (long)split * chunk, p_end = (p_beg + chunk < n) ? p_beg + chunk : n;
     float* o = part + ((size_t)seg * gridDim.x + split) * C * C;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) tri_main<0>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
-    else if (wave == 1) tri_main<1>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
-    else if (wave == 2) tri_main<2>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
-    else tri_main<3>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+    if (wave == 0) tri_main<NB, 0>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+    else if (wave == 1) tri_main<NB, 1>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+    else if (wave == 2) tri_main<NB, 2>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
+    else tri_main<NB, 3>(xs, ld, n, C, mus, p_beg, p_end, o, g_smem);
 }
 
 // cov[s][i][j] = sum_split part / N + eps * (i == j); lower triangle mirrored from the upper tiles.
@@ -419,6 +427,26 @@ __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n
 
 int device_cu_count();
 bool gram_tri_enabled = true;  // (internal, not ABI: tests compare the whole-triangle kernel with the tile-pair kernel)
+
+template <int NB>
+static int launch_tri(const float* x, long ld, long seg_stride, long n, int C, const float* mu, long chunk, float* part, int splits,
+                      int n_seg, hipStream_t st) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tri_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)tri_lds_bytes(NB));
+        if (e != hipSuccess) {
+            set_error("gram_tri_kernel: cannot reserve LDS: %s", hipGetErrorString(e));
+            return OPTEX_E_LAUNCH;
+        }
+        attr_done[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(gram_tri_kernel<NB>, dim3(splits, n_seg), dim3(256), tri_lds_bytes(NB), st, x, ld, seg_stride, n, C, mu, chunk,
+                       part);
+    return OPTEX_OK;
+}
 
 static int gram_splits(long n, int C, int n_seg, bool big) {
     // 64-tiles: two blocks' worth of work per CU; 128-tiles (two resident blocks per CU, long blocks): about four rounds of
@@ -471,7 +499,7 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
     int rc = check_launch("col_mean_kernel");
     if (rc) return rc;
     const bool big = C > GT && vec && n % 4 == 0;  // the 128-tile kernel loads unconditional float4s
-    const bool tri = big && C > 192 && C <= TRI_ROWS && gram_tri_enabled;
+    const bool tri = big && C > 128 && C <= 256 && gram_tri_enabled;
     const int gt = big ? GT2 : GT;
     const int tiles = (C + gt - 1) / gt, pairs = tiles * (tiles + 1) / 2;
     int splits = gram_splits(n, C, n_seg, big);
@@ -491,19 +519,9 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
         const int b64 = (C + GT - 1) / GT;
         ProfScope prof(KC_GRAM, st, 2.0 * (b64 * (b64 + 1) / 2) * GT * GT * (double)n * n_seg, 4.0 * (double)n * C * n_seg);
         if (tri) {
-            static bool tri_attr[64] = {};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (!tri_attr[dev & 63]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tri_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS);
-                if (e != hipSuccess) {
-                    set_error("gram_tri_kernel: cannot reserve LDS: %s", hipGetErrorString(e));
-                    return OPTEX_E_LAUNCH;
-                }
-                tri_attr[dev & 63] = true;
-            }
-            hipLaunchKernelGGL(gram_tri_kernel, dim3(splits, n_seg), dim3(256), TRI_LDS, st, x, ld, seg_stride, n, C, mu, chunk, part);
+            if (C > 192) rc = launch_tri<8>(x, ld, seg_stride, n, C, mu, chunk, part, splits, n_seg, st);
+            else rc = launch_tri<6>(x, ld, seg_stride, n, C, mu, chunk, part, splits, n_seg, st);
+            if (rc) return rc;
         } else if (big) {
             constexpr int gk = 32;
             const size_t lds = (size_t)4 * GT2 * (gk + 1) * sizeof(float);

@@ -526,9 +526,11 @@ def test_linear_stats_vs_fp64(dev, S, C, n, pool):
 
 
 @pytest.mark.parametrize("S,C,n,pool", [(3, 256, 4096, False), (2, 256, 16384, True), (2, 200, 1000, False), (1, 224, 6400, False),
-                                         (5, 193, 260, False), (1, 256, 36, False)])
+                                         (5, 193, 260, False), (1, 256, 36, False), (2, 184, 4096, False), (3, 160, 1000, True),
+                                         (1, 132, 260, False), (2, 192, 16384, False)])
 def test_linear_stats_whole_triangle_kernel(dev, S, C, n, pool):
-    """192 < C <= 256: one workgroup computes the 36 upper 32 x 32 tiles of a segment's Gram matrix (gram_tri_kernel).
+    """128 < C <= 256 (rows 16-byte aligned): one workgroup computes the 36 (C > 192) or 21 upper 32 x 32 tiles of a segment's
+    Gram matrix (gram_tri_kernel).
     Against numpy fp64, and against the tile-pair kernel it replaces (`optex::gram_tri_enabled`, an internal switch of the
     library, not ABI) — different split-K partitions, so equal to round-off, not bit for bit."""
     import ctypes
