@@ -200,6 +200,7 @@ def dry_run(args, rank, world, device):
 
 
 def main():
+    t_main = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -474,6 +475,7 @@ def main():
             threads = min(os.cpu_count() or 1, 32)
             result["cpu_baseline"] = cpu_baseline(args.hist_mode, threads)
     if rank == 0:
+        result["bench_wall_s"] = round(time.perf_counter() - t_main, 1)  # the whole command, extra rows and CPU baseline included
         print(json.dumps(result))
 
 

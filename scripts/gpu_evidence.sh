@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 STAMP="round 3, commit $COMMIT, one MI355X"
 ( timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "rc=$?" >> $OUT/bench_default.err )
 tail -c 400 $OUT/bench_default.json; echo
-for MODE in cdf sort chol; do
+for MODE in cdf sort chol sym; do
   ( timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$MODE -o prof -- python bench.py --hist_mode $MODE --steps 2 --warmup 1 --no_cpu_baseline --other_modes "" > $OUT/prof_$MODE.log 2>&1; echo "rc=$?" >> $OUT/prof_$MODE.log )
   python scripts/summarize_rocprof.py $OUT/prof_$MODE/prof_kernel_trace.csv --warmup 1 --title "bench.py --hist_mode $MODE, 64 textures per step ($STAMP)" --out $OUT/bench_b64_${MODE}_kernel_summary.md > /dev/null 2>&1
   rm -rf $OUT/prof_$MODE
@@ -21,6 +21,12 @@ done
 ( timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_pca -o prof -- python bench.py --hist_mode chol --pca --steps 2 --warmup 1 --no_cpu_baseline --other_modes "" > $OUT/prof_pca.log 2>&1; echo "rc=$?" >> $OUT/prof_pca.log )
 python scripts/summarize_rocprof.py $OUT/prof_pca/prof_kernel_trace.csv --warmup 1 --title "bench.py --hist_mode chol --pca (the reference's default flags, independent textures), 64 textures per step ($STAMP)" --out $OUT/bench_b64_pca_kernel_summary.md > /dev/null 2>&1
 rm -rf $OUT/prof_pca
+( timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_single -o prof -- python scripts/single_latency.py 3 > $OUT/prof_single.log 2>&1; echo "rc=$?" >> $OUT/prof_single.log )
+python scripts/summarize_rocprof.py $OUT/prof_single/prof_kernel_trace.csv --title "ONE texture, B = 1, relu5_1..relu1_1, PCA, chol, 493 OT iterations (the reference's default command line): 3 calls incl. the first ($STAMP)" --out $OUT/single_texture_kernel_summary.md > /dev/null 2>&1
+rm -rf $OUT/prof_single
+grep "^call" $OUT/prof_single.log
+( timeout 300 python scripts/gram_probe.py > $OUT/gram_probe.md 2>&1 )
+( timeout 300 python scripts/ns_count_probe.py > $OUT/ns_count_probe.md 2>&1 )
 head -24 $OUT/bench_b64_cdf_kernel_summary.md
 for MODE in cdf sort; do
   for CTR in FETCH_SIZE WRITE_SIZE; do
