@@ -22,7 +22,7 @@ done
 python scripts/summarize_rocprof.py $OUT/prof_pca/prof_kernel_trace.csv --warmup 1 --title "bench.py --hist_mode chol --pca (the reference's default flags, independent textures), 64 textures per step ($STAMP)" --out $OUT/bench_b64_pca_kernel_summary.md > /dev/null 2>&1
 rm -rf $OUT/prof_pca
 ( timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_single -o prof -- python scripts/single_latency.py 3 > $OUT/prof_single.log 2>&1; echo "rc=$?" >> $OUT/prof_single.log )
-python scripts/summarize_rocprof.py $OUT/prof_single/prof_kernel_trace.csv --title "ONE texture, B = 1, relu5_1..relu1_1, PCA, chol, 493 OT iterations (the reference's default command line): 3 calls incl. the first ($STAMP)" --out $OUT/single_texture_kernel_summary.md > /dev/null 2>&1
+python scripts/summarize_rocprof.py $OUT/prof_single/prof_kernel_trace.csv --all --title "ONE texture, B = 1, relu5_1..relu1_1, PCA, chol, 493 OT iterations (the reference default command line): 3 calls incl. the first ($STAMP)" --out $OUT/single_texture_kernel_summary.md > /dev/null 2>&1
 rm -rf $OUT/prof_single
 grep "^call" $OUT/prof_single.log
 ( timeout 300 python scripts/gram_probe.py > $OUT/gram_probe.md 2>&1 )
