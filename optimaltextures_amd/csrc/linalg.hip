@@ -374,17 +374,28 @@ __device__ __forceinline__ double ns_l0(float lambda_min, double fro) {
 // iteration polishes.  The launch-wide count (the largest need, made even so that the ping-pong ends in the same buffers
 // as the full count) is taken with an atomic: the host enqueues NS_ITERS iterations and the later ones switch themselves
 // off (GemmArgs::live_until) — no device-to-host round trip.
+constexpr int NS_INIT_PARTS = 4;
 __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ A, long a_ss, int C, int batch, int K,
                                                       int adaptive, float lambda_min, float* __restrict__ Y,
                                                       float* __restrict__ Z, float* __restrict__ fro_out,
                                                       int* __restrict__ k_need) {
-    const int b = blockIdx.x;
+    // grid = (batch, NS_INIT_PARTS): every part takes the norm of the whole matrix (the same sum in the same order, so all parts
+    // scale by the same value) and writes its share of the rows of Y0 and Z0 — 4 x batch workgroups instead of batch
+    const int b = blockIdx.x, part = blockIdx.y;
     const float* Ab = A + (size_t)b * a_ss;
-    const size_t cc = (size_t)C * C;
+    const int cc = C * C;
     double s = 0.0;
-    for (size_t i = threadIdx.x; i < cc; i += blockDim.x) {
-        const double v = (double)Ab[i];
-        s += v * v;
+    if (cc % 4 == 0 && (reinterpret_cast<uintptr_t>(Ab) & 15) == 0) {
+        const float4* A4 = reinterpret_cast<const float4*>(Ab);
+        for (int i = threadIdx.x; i < cc / 4; i += 256) {
+            const float4 v = A4[i];
+            s += ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < cc; i += 256) {
+            const double v = (double)Ab[i];
+            s += v * v;
+        }
     }
     s = wave_sum(s);
     __shared__ double sh[4];
@@ -394,7 +405,10 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) {
         const double fro = sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
         fro_s = (float)fro;
-        fro_out[b] = fro_s;
+    }
+    if (threadIdx.x == 0 && part == 0) {
+        const double fro = sqrt((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        fro_out[b] = (float)fro;
         double l = ns_l0(lambda_min, fro);
         int need = 0;
         while (need < K && l < 1.0 - 6e-8) {
@@ -410,10 +424,12 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
     const float fro = fro_s;
     float* Yb = Y + (size_t)b * cc;
     float* Zb = Z + (size_t)b * cc;
-    for (size_t i = threadIdx.x; i < cc; i += blockDim.x) {
-        Yb[i] = __fdiv_rn(Ab[i], fro);
-        Zb[i] = (i / C == i % C) ? 1.f : 0.f;
-    }
+    const int rows = (C + NS_INIT_PARTS - 1) / NS_INIT_PARTS, r0 = part * rows, r1 = (r0 + rows < C) ? r0 + rows : C;
+    for (int r = r0 + (threadIdx.x >> 6); r < r1; r += 4)       // (no integer division per element: it was most of this kernel)
+        for (int c = threadIdx.x & 63; c < C; c += 64) {
+            Yb[r * C + c] = __fdiv_rn(Ab[r * C + c], fro);
+            Zb[r * C + c] = (r == c) ? 1.f : 0.f;
+        }
 }
 
 // the per-matrix coefficients of the *k_need iterations that run:
@@ -470,7 +486,7 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float
     }
     {
         ProfScope prof(KC_NS_INIT, st, 0.0, 12.0 * (double)cc * batch);
-        hipLaunchKernelGGL(ns_init_kernel, dim3(batch), dim3(256), 0, st, A, a_ss, C, batch, K, ns_adaptive ? 1 : 0,
+        hipLaunchKernelGGL(ns_init_kernel, dim3(batch, NS_INIT_PARTS), dim3(256), 0, st, A, a_ss, C, batch, K, ns_adaptive ? 1 : 0,
                            lambda_min, Y, Z, fro, k_need);
         hipLaunchKernelGGL(ns_coef_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, fro, batch, lambda_min, k_need, cw, cy, cz);
     }
