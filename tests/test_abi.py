@@ -50,6 +50,27 @@ def test_argument_errors_are_reported_without_launching():
     assert b"C % 4" in lib.optex_last_error()
 
 
+def test_round3_entry_points_check_their_arguments_without_launching():
+    """optex_cdf_match_bins (ABI 6) and the collapsed chain of optex_ot_loop (fuse_rotations = 3) refuse bad calls on the host"""
+    import ctypes
+    lib = _lib.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    C, S, n, ns = 8, 2, 64, 48
+    assert lib.optex_cdf_match_bins(p, n, C * n, n, p, ns, C * ns, ns, 1, C, S, 0, p, n, C * n, p, 1 << 20, None) == -1
+    assert b"optex_cdf_match_bins" in lib.optex_last_error() and b"bins=0" in lib.optex_last_error()
+    assert lib.optex_cdf_match_bins(p, n, C * n, n, p, ns, C * ns, ns, 3, C, S, 16, p, n, C * n, p, 1 << 20, None) == -1
+    need = lib.optex_cdf_bins_ws_bytes(C, S, 5000)
+    assert lib.optex_cdf_match_bins(p, n, C * n, n, p, ns, C * ns, ns, 1, C, S, 5000, p, n, C * n, p, need - 1, None) == -1
+    assert b"scratch buffer too small" in lib.optex_last_error()
+    # collapsed chain: linear modes only, no content blend
+    for mode, content in ((0, None), (1, None), (2, p)):
+        rc = lib.optex_ot_loop(mode, p, n, S, p, ns, 1, C, p, p, 0, 2, content, 0.1, 3, p, 1 << 30, None)
+        assert rc == -1 and b"collapsed chain" in lib.optex_last_error(), mode
+    assert lib.optex_ot_loop(2, p, n, S, p, ns, 1, C, p, p, 0, 2, None, 0.0, 4, p, 1 << 30, None) == -1
+    assert lib.optex_ot_loop_ws_bytes(2, n, ns, C, S, 1, 2, 3, 0) > lib.optex_ot_loop_ws_bytes(2, n, ns, C, S, 1, 2, 1, 0)
+
+
 def test_undersized_scratch_is_refused_before_any_launch():
     """ABI 3: every entry point that takes `ws` also takes `ws_bytes` and refuses a buffer smaller than its *_ws_bytes
     helper asks for (ABI 2 trusted the pointer: an undersized buffer was silent device-memory corruption)."""
