@@ -244,3 +244,48 @@ def test_sort_match_is_exact_1d_transport():
         ss = np.sort(s2[c])
         r = np.argsort(np.argsort(t[c], kind="stable"), kind="stable")
         assert np.array_equal(out2[c], ss[((2 * r + 1) * 300) // (2 * 512)])
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 7.4-3 on the oracle
+@pytest.mark.parametrize("mode", ["chol", "pca", "sym"])
+def test_collapsed_linear_chain_is_the_literal_chain(mode):
+    """The algebra behind optex_ot_loop(fuse_rotations = 3), checked on the CPU restatement alone: a chain of linear-mode
+    steps x' = hist_match(x R, s R) R^T equals ONE affine map M_k ... M_1 (x - mean(x)) + mean(s) with M_i = R_i T_i R_i^T,
+    where the covariance every later step sees follows analytically, cov(x') = M_i cov(x) M_i^T (no pass over the map)."""
+    rng = np.random.default_rng(11)
+    C, n, ns, iters = 12, 900, 700, 6
+    x = np.maximum(rng.standard_normal((C, n)) * 2 + 0.3, 0).astype(np.float32)
+    s = np.maximum(rng.standard_normal((C, ns)) * 1.5 + 0.5, 0).astype(np.float32)
+    lr = orc.LegacyRNG(5)
+    Rs = [orc.random_rotation(C, lr) for _ in range(iters)]
+    # literal chain (optex.py:112-117 without a content blend)
+    w = x
+    for R in Rs:
+        w = orc.unrotate_cm(orc.linear_match(orc.rotate_cm(w, R), 1, orc.rotate_cm(s, R), 1, mode), R)
+    # collapsed chain in fp64: statistics only
+    x64, s64 = x.astype(np.float64), s.astype(np.float64)
+    mu_x, mu_s = x64.mean(1, keepdims=True), s64.mean(1, keepdims=True)
+    cov = (x64 - mu_x) @ (x64 - mu_x).T / n
+    cov_s = (s64 - mu_s) @ (s64 - mu_s).T / ns
+    eye = np.eye(C)
+
+    def sqrtm(a):
+        ev, v = np.linalg.eigh(a)
+        return (v * np.sqrt(ev)) @ v.T
+
+    acc = eye
+    for R in Rs:
+        ct, cs = R.T @ cov @ R + eye, R.T @ cov_s @ R + eye       # cov(x R) = R^T cov(x) R; eps * I is rotation-invariant
+        if mode == "chol":
+            T = np.linalg.cholesky(cs) @ np.linalg.inv(np.linalg.cholesky(ct))
+        elif mode == "pca":
+            T = sqrtm(cs) @ np.linalg.inv(sqrtm(ct))
+        else:
+            qt = sqrtm(ct)
+            qi = np.linalg.inv(qt)
+            T = qi @ sqrtm(qt @ cs @ qt) @ qi
+        M = R @ T @ R.T
+        cov = M @ cov @ M.T
+        acc = M @ acc
+    got = acc @ (x64 - mu_x) + mu_s
+    assert np.abs(got - w).max() <= 2e-4 * np.abs(w).max()
