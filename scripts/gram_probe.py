@@ -10,7 +10,8 @@ dev = torch.device("cuda:0")
 flag = ctypes.c_bool.in_dll(_lib.lib(), "_ZN5optex16gram_tri_enabledE")
 print("| C | n | segments | whole-triangle us | tile-pair us | TFLOP/s on C (C + 1) n flops (whole-triangle / tile-pair) |")
 print("|---:|---:|---:|---:|---:|---|")
-for C, n, S in ((256, 16384, 64), (256, 12544, 64), (256, 9216, 64), (256, 6400, 64), (256, 4096, 64), (256, 16384, 8), (256, 16384, 1),
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]  # optional "C,n,S" triples instead of the default list
+for C, n, S in shapes or ((256, 16384, 64), (256, 12544, 64), (256, 9216, 64), (256, 6400, 64), (256, 4096, 64), (256, 16384, 8), (256, 16384, 1),
                 (224, 16384, 64), (200, 4096, 64), (184, 16384, 64), (184, 4096, 64), (168, 9216, 64), (136, 16384, 64)):
     x = torch.randn((S, C, n), device=dev).clamp_min(0)
     res = {}
