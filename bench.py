@@ -179,7 +179,7 @@ def spawn_ranks(n):
 def dry_run(args, rank, world, device):
     """the launch path without the GPU work: every rank walks its rotation groups / texture indices step by step, the timed
     region is bracketed by the same barrier + max-over-ranks reduction as the real run"""
-    B = args.batch
+    B = args.total // world if args.total else args.batch
     mine = []
     t0 = time.perf_counter()
     for k in range(args.warmup + args.steps):
@@ -192,7 +192,8 @@ def dry_run(args, rank, world, device):
     if rank == 0:
         print(json.dumps({"metric": "512^2 textures/sec (relu3_1, default iters)", "value": None, "unit": "textures/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "dry_run": True,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "strong" if args.total else "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "dry run: launch path only", "textures_per_gpu_per_step": B,
                                      "parallelism": f"textures x{world}"},
                           "first_timed_texture_by_rank": [int(f) for f in firsts], "textures_total": B * world * args.steps,
@@ -206,8 +207,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="independent textures per GPU per step (16 / 32 / 64 measured: 176 / 183 / 198 textures/s)")
+    ap.add_argument("--total", type=int, default=0,
+                    help="STRONG scaling (BASELINE config 4 as written: --total 64 --gpus 8 = 8 textures per GPU): the job's textures "
+                         "per step, split evenly over the ranks (overrides --batch; the JSON line then says \"scaling\": \"strong\")")
     ap.add_argument("--hist_mode", type=str, default="cdf", choices=["cdf", "sort", "chol", "pca", "sym"])
-    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,fused,pcadefault,ownrotations,refdefaults,assets,single",
+    ap.add_argument("--other_modes", type=str, default="sort,chol,pca,sym,batch8,fused,pcadefault,ownrotations,refdefaults,assets,single",
                     help="one extra step each (N = 1 only); 'fused' = the labelled re-association fast paths, "
                          "'refdefaults' = chol + PCA + pooled batch (the reference's own defaults), 'assets' = the headline "
                          "configuration on the reference's real relu3_1 weights and style/graffiti.jpg (assets/)")
@@ -237,6 +241,8 @@ def main():
     rank, world, device = otdist.init_distributed("gloo" if args.dry_run and not torch.cuda.is_available() else None)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.total and args.total % world:
+        raise SystemExit(f"bench.py: --total {args.total} does not split evenly over {world} ranks")
     if args.dry_run:
         return dry_run(args, rank, world, device)
     if device.type != "cuda":
@@ -244,6 +250,8 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find  # MIOpen find mode: the VGG convs are the largest non-hot-path cost
 
     B = args.batch
+    if args.total:
+        B = args.total // world  # a rank's shard of the step: one rotation group (dist.py), like a weak-mode step of that size
     style = synthetic_style(device)
     tex = make_texturizer(args.hist_mode, device, no_pca=not args.pca)
     if world > 1:
@@ -280,6 +288,8 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         gc.enable()
+        if tex.style_sync is not None:
+            tex.style_sync.verify(block=True)  # a style payload its source had marked invalid raises on EVERY rank, here at the latest
         ops.profile_enable(False)
         prof = {} if args.no_kernel_timing else ops.profile_collect()
         assert torch.isfinite(out).all()
@@ -291,7 +301,8 @@ def main():
     result = {
         "metric": "512^2 textures/sec (relu3_1, default iters)", "value": round(value, 3), "unit": "textures/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.total else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
         "config": {"workload": f"{B} independent 512^2 textures per GPU per step, VGG relu3_1 only, {'C=k (PCA on)' if args.pca else 'C=256 (no_pca)'}, "
                                f"5 passes 256..512, 52 OT iterations (default iters=500), hist_mode={args.hist_mode}, "
                                "style 736x512 synthetic, random-init VGG weights",
@@ -348,6 +359,26 @@ def main():
                                          "one launch of 256 workgroups, latency-bound by construction")
                     result["sort_kernels"] = sk
         result["textures_per_s_by_hist_mode"] = by_mode
+        if "batch8" in args.other_modes.split(",") and B != 8:
+            # BASELINE config 4 as written shards 64 textures 8 per GPU: the per-GPU shard of that STRONG-scaling job on one
+            # GPU (what `--total 64 --gpus 8` runs on every rank), several steps because one is short
+            with torch.inference_mode():
+                def step8():
+                    q = counter["step"]
+                    counter["step"] += 1
+                    tex.rng = otdist.rotation_rng(args.seed, q)
+                    return tex.forward(otdist.texture_noise(q * 8, 8, (3, SIZE, SIZE), device, seed=args.seed), [style])
+
+                for _ in range(2):
+                    step8()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(6):
+                    step8()
+                torch.cuda.synchronize()
+                result["textures_per_s_batch8"] = {
+                    "value": round(6 * 8 / (time.perf_counter() - t0), 3),
+                    "config": f"8 independent textures per step (config 4's per-GPU shard), hist_mode={args.hist_mode}, otherwise the headline configuration; 6 timed steps"}
         if "fused" in args.other_modes.split(","):
             # labelled fast paths, NOT the headline.  cdf / sort: (m @ R^T) @ R' re-associated to m @ (R^T R'), one
             # feature-map GEMM per iteration instead of two; chol: the whole step as one affine map in un-rotated space

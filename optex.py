@@ -70,6 +70,11 @@ def build_parser():
                         "with seeded random weights instead of raising FileNotFoundError")
     p.add_argument("--independent", action="store_true", help="--batch images are independent textures (not pooled)")
     p.add_argument("--np_seed", type=int, default=None, help="seed numpy's global RNG (drives the rotations)")
+    p.add_argument("--pca_fit", type=str, default="gram", choices=["gram", "svd"],
+                   help="how fit_pca finds its basis: eigenvectors of the fp64 Gram matrix (default, fast on ROCm) or the "
+                        "reference's literal torch.linalg.svd call (optex.py:183) for parity runs")
+    p.add_argument("--codec_layout", type=str, default="mixed", choices=["mixed", "nchw"],
+                   help="memory layout of the VGG convolutions inside the fused codec path (vgg.py)")
     return p
 
 
@@ -80,14 +85,17 @@ def main(argv=None):
     rank, world, device = otdist.init_distributed()
     if device.type != "cuda":
         raise SystemExit("optex.py needs an MI355X: the HIP path has no CPU fallback")
-    # One seeding rule for sharded runs (optimaltextures_amd/dist.py): every rank seeds torch and numpy identically — all
-    # ranks then share one rotation stream and one mixing mask, as the reference's single process does (optex.py:149,
-    # 253-254) — and with --independent texture i's noise comes from its own generator, texture_seed(seed, i): the job
-    # writes the same images on 1, 2, 4 or 8 GPUs.
+    # Seeding (optimaltextures_amd/dist.py).  --independent (an extension: the reference has no such flag): every rank seeds
+    # torch and numpy identically and texture i's noise comes from its own generator, texture_seed(seed, i) — the job writes
+    # the same images on 1, 2, 4 or 8 GPUs (and therefore NOT the reference's single `torch.rand(batch, ...)` draw, not even
+    # on one GPU: INTEGRATION.md).  Without --independent (pooled --batch, content image) a multi-rank run is N replicas of
+    # the job: rank r seeds with seed + r / np_seed + r, so the ranks write N different variants, not N copies of one
+    # image; rank 0 — and any single-process run — is the reference's own draw (optex.py:253-254, 263-265).
+    variant = rank if (world > 1 and not args.independent) else 0
     if args.seed is not None:
-        torch.manual_seed(args.seed)
+        torch.manual_seed(args.seed + variant)
     if args.np_seed is not None:
-        np.random.seed(args.np_seed)
+        np.random.seed(args.np_seed + variant)
 
     if world > 1 and args.independent and args.batch < world:
         raise SystemExit(f"--independent --batch {args.batch} cannot be sharded over {world} ranks: every rank needs at "
@@ -112,7 +120,7 @@ def main(argv=None):
             color_transfer=args.color_transfer, content_strength=args.content_strength, style_scale=args.style_scale,
             mixing_alpha=args.mixing_alpha, no_pca=args.no_pca, no_multires=args.no_multires, layers=args.layers,
             models_dir=resolve(args.models_dir), independent=args.independent,
-            allow_synthetic=args.synthetic_weights).to(device)
+            allow_synthetic=args.synthetic_weights, codec_layout=args.codec_layout, pca_fit=args.pca_fit).to(device)
         if rank == 0:
             for enc, dec in zip(texturizer.encoders, texturizer.decoders):
                 print(f"relu{enc.depth}_1 weights: encoder {enc.weights} | decoder {dec.weights}")
@@ -122,6 +130,8 @@ def main(argv=None):
         t = time()
         pastiche = texturizer.forward(pastiche, styles, content, verbose=rank == 0)
         torch.cuda.synchronize()
+        if texturizer.style_sync is not None:
+            texturizer.style_sync.verify(block=True)
         if rank == 0:
             print("Took:", time() - t)
     if world > 1 and args.independent:

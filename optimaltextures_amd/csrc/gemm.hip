@@ -484,9 +484,10 @@ static int launch_cfg(GemmArgs& a, bool vec, hipStream_t st) {
 //   256x128 tile / 512 threads  113 TFLOP/s   <- whole M in one block: the feature map is read from HBM exactly once
 //   128x128 tile / 256 threads  109 TFLOP/s      (every pixel tile is fetched by two m-tiles)
 // Software-pipelined LDS fragment reads, LDS refill under the MFMAs, BK = 8 / 32, and an LDS-free variant streaming
-// fragments straight from L1/L2 were all tried and measured 72-99 TFLOP/s.  The kernel is issue-bound (one barrier per
-// 16-deep K chunk with two waves per SIMD: SQ_WAIT_INST_ANY 0.68), not power-limited: 1243 W mean of the 1400 W cap at
-// top clock (profiles/r02_power_gemm_rocm_smi.md).
+// fragments straight from L1/L2 were all tried and measured 72-99 TFLOP/s.  What bounds it (round 3, DESIGN.md 4.1,
+// profiles/r03_gemm_power_dvfs.md): MFMA duty cycle 0.73-0.77 whatever the data, at the clock the power management allows
+// for that data — 2.39 GHz on an all-zero feature map, 2.12 GHz on a dense (gaussian) one.  Round 2's "not power-limited,
+// 1243 W at top clock" was a rocm-smi sample (0.28 s) over half-zero features and is withdrawn.
 int device_cu_count();
 
 // (internal, not ABI: scripts/gemm_rs_probe.hip times the kernels against each other at every shape)

@@ -38,7 +38,8 @@ bool gemm_rowstat_supported(const GemmArgs& a);
 // partials per (segment, row) a rowstat launch writes for n pixels
 int gemm_rowstat_parts(long n);
 
-// the R-stationary, LDS-free hot-loop kernel (gemm_rs.hip): channel-major in / out, 128 < M, K <= 256, n % 64 == 0
+// the R-stationary, LDS-free hot-loop kernel (gemm_rs.hip): channel-major in / out, 64 < M <= 256, 64 <= K <= 256, n % 64 == 0
+// (bsub: M <= 192 only; row statistics: without bsub / badd / content only — gemm_rs_supported is the authority)
 bool gemm_rs_supported(const GemmArgs& a, int n_cu);
 int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st);
 extern bool gemm_rs_enabled, gemm_rs_force;

@@ -4,14 +4,16 @@
 //
 // The left operand of every rotation is a C x C matrix (C <= 256) shared by all pixels of a segment; the right operand, the
 // feature map, streams through once.  gemm16_cm_kernel (gemm.hip) stages both through LDS in 16-deep K chunks: one barrier
-// per chunk with two waves per SIMD, 0.73-0.76 of the fp32-MFMA peak, issue-bound.  This kernel removes the
-// staging instead of tuning it:
+// per chunk with two waves per SIMD, 0.73-0.76 of the fp32-MFMA peak.  This kernel removes the staging instead of tuning it
+// — and lands on the same TFLOP/s: both kernels keep the matrix pipe busy 0.73-0.77 of the cycles and run at the clock the
+// power management allows for the data (2.39 GHz on zeros, 2.12 GHz on dense operands; DESIGN.md 4.1,
+// profiles/r03_gemm_power_dvfs.md):
 //
 //   * one workgroup of four wavefronts per CU (one wave per SIMD, the whole 512-register file), PERSISTENT over a contiguous
 //     range of pixel tiles;
 //   * wave w owns the output rows [16 MT w, 16 MT (w + 1)) and keeps its slice of the matrix — MT x KS fragments of
-//     v_mfma_f32_16x16x4_f32's A operand, up to 256 registers — for the whole launch (reloaded only when the segment, and
-//     with it the matrix, changes);
+//     v_mfma_f32_16x16x4_f32's A operand, up to 256 registers — for the whole launch (a workgroup never crosses matrices:
+//     with per-segment matrices the grid's y dimension selects the segment, so there is no reload);
 //   * the feature map goes from HBM straight into the MFMA's B-operand registers: lane (i = lane & 15, q = lane >> 4) loads
 //     the 16 bytes B[4 ks + q][p0 + 4 i .. + 3] of k-step ks — component j of that float4 IS the fragment of pixel sub-tile j
 //     (sub-tile j = pixels p0 + 4 i + j: which 16 pixels form a 16-column MFMA tile is free to choose), so one
@@ -275,7 +277,9 @@ bool gemm_rs_supported(const GemmArgs& a, int n_cu) {
     if (!rs_aligned16(a.B) || a.ldb % 4 != 0 || a.b_ss % 4 != 0) return false;
     if (!rs_aligned16(a.O) || a.ldo % 4 != 0 || a.o_ss % 4 != 0) return false;
     if (a.content && !rs_aligned16(a.content)) return false;
-    if ((unsigned long long)a.ldb * 4ull + 64ull >= (1ull << 32)) return false;  // 32-bit lane offsets
+    // 32-bit lane offsets: a lane addresses row kq <= 3 of a k-step, ((kq * ldb + 4 * l15) * 4) bytes past the wave's base
+    if (12ull * (unsigned long long)a.ldb + 256ull >= (1ull << 32)) return false;
+    if (a.rowstat && (a.bsub || a.badd || a.content)) return false;  // the row statistics ride in the plain epilogue only
     const long long total = (long long)(a.n / RS_BN) * a.n_seg;
     return total >= 2LL * n_cu;  // every CU streams at least two tiles behind one matrix load
 }
@@ -285,8 +289,17 @@ int gemm_rs_parts(long n) { return (int)(n / RS_BN); }
 template <int MT, int KS>
 static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
     const GemmArgs& a = ra.g;
+    if (a.rowstat && (a.bsub || a.badd || a.content)) {
+        set_error("gemm_rs_kernel: row statistics cannot be combined with bsub / badd / content (gemm_rs_supported says so)");
+        return OPTEX_E_UNSUPPORTED;
+    }
     if (a.bsub) {
-        if constexpr (MT <= 3) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2>), grid, dim3(256), 0, st, ra);
+        if constexpr (MT <= 3) {
+            hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2>), grid, dim3(256), 0, st, ra);
+        } else {  // four row tiles per wave leave no registers for the centring ring: never launched silently as a no-op
+            set_error("gemm_rs_kernel: bsub with M > 192 is not built (gemm_rs_supported says so)");
+            return OPTEX_E_UNSUPPORTED;
+        }
     } else if (a.badd || a.content)
         hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1>), grid, dim3(256), 0, st, ra);
     else if (a.rowstat == 1)

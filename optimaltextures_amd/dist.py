@@ -55,7 +55,14 @@ class StyleSync:
     The header has no fixed capacity: it is sized from `counts = (n_tensors, n_ints)`, which the caller passes when every
     rank can compute them (OptimalTexture.forward: 2 * passes * layers tensors); without `counts` a two-integer message
     announces them first.  Nothing is checked on one rank only between collectives: a source whose lists do not match the
-    announced counts marks the header, the exchange completes, and EVERY rank raises."""
+    announced counts marks the header, the exchange completes, and EVERY rank raises.  The header-free exchange
+    (broadcast_known) carries its mark in the first word of the payload: the source raises at once, a receiver as soon as it
+    has looked at the word — immediately on a host backend (gloo), and on a GPU without ever blocking the host: the word is
+    copied to pinned memory behind the broadcast and examined by `verify()`, which every later exchange calls first and
+    which a caller can make blocking where it synchronises anyway (bench.py: after the timed region; optex.py: before
+    saving).  No rank is left computing on a marked payload past its next exchange."""
+
+    STATUS_WORDS = 64  # the mark travels in front of the payload; 64 floats keep every tensor on its 256-byte boundary
 
     def __init__(self, device, src: int = 0, group=None, always: bool = False):
         """always=True: issue the broadcasts even in a world of one (tests: the RCCL call sequence on one GPU)"""
@@ -64,6 +71,23 @@ class StyleSync:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_moved = 0    # payload + header bytes this rank sent or received
         self.messages = 0       # broadcast calls issued
+        self._pending = []      # (pinned host word, event) of header-free exchanges whose mark has not been looked at yet
+
+    def verify(self, block: bool = False):
+        """Raise ValueError if a header-free exchange delivered a payload its source had marked as not matching the announced
+        shapes.  block=False looks only at marks whose copy has completed (never waits); block=True waits for all of them."""
+        keep, bad = [], False
+        for host, ev in self._pending:
+            if ev is not None and not block and not ev.query():
+                keep.append((host, ev))
+                continue
+            if ev is not None:
+                ev.synchronize()
+            bad = bad or float(host[0]) != 0.0
+        self._pending = keep
+        if bad:
+            raise ValueError("StyleSync.broadcast_known: the source rank's tensors did not have the announced shapes "
+                             "(the payload of that exchange was marked invalid)")
 
     @property
     def is_source(self) -> bool:
@@ -79,31 +103,45 @@ class StyleSync:
         enqueueing kernels behind it.  source: list of fp32 tensors of exactly these shapes -> everyone: the tensors."""
         if self.world == 1 and not self.always:
             return list(tensors)
+        self.verify()
         numels = [int(torch.Size(sh).numel()) for sh in shapes]
-        total = sum(_padded(k) for k in numels)
+        head = self.STATUS_WORDS
+        total = head + sum(_padded(k) for k in numels)
         flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        bad = False
         if self.is_source:
             bad = tensors is None or len(tensors) != len(shapes) or any(tuple(t.shape) != tuple(sh) or t.dtype != torch.float32
                                                                        for t, sh in zip(tensors or [], shapes))
             if bad:
-                # the payload still goes out (nobody is left waiting in a collective); a NaN in the first word marks it
+                # the payload still goes out (nobody is left waiting in a collective), marked: word 0 != 0, the rest NaN
                 flat.fill_(float("nan"))
+                flat[:head] = 1.0
             else:
-                off = 0
+                flat[:head] = 0.0
+                off = head
                 for t, k in zip(tensors, numels):
                     flat[off:off + k].copy_(t.reshape(-1))
                     off += _padded(k)
-        work = dist.broadcast(flat, self.src, group=self.group, async_op=True) if total else None
-        self.messages += 1 if total else 0
+        work = dist.broadcast(flat, self.src, group=self.group, async_op=True)
+        self.messages += 1
         self.bytes_moved += total * 4
-        out, off = [], 0
+        out, off = [], head
         for sh, k in zip(shapes, numels):
             out.append(flat[off:off + k].view(tuple(sh)))
             off += _padded(k)
-        if work is not None:
-            work.wait()  # RCCL: the current stream waits for the communicator's stream, the host does not block
+        work.wait()  # RCCL: the current stream waits for the communicator's stream, the host does not block
         if self.is_source and bad:
             raise ValueError("StyleSync.broadcast_known: the source rank's tensors do not have the announced shapes")
+        if flat.is_cuda:
+            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host.copy_(flat[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((host, ev))
+            self.verify()
+        else:
+            self._pending.append((flat[:1], None))
+            self.verify(block=True)
         return out
 
     def broadcast_packed(self, tensors: Optional[List[torch.Tensor]], ints: Optional[List[int]] = None,
@@ -112,6 +150,7 @@ class StyleSync:
         counts = (n_tensors, n_ints) if known on every rank (saves the announcing message)."""
         if self.world == 1 and not self.always:
             return list(tensors), list(ints or [])
+        self.verify()
         if self.is_source:
             ints = [int(v) for v in (ints or [])]
             tensors = list(tensors or [])

@@ -61,10 +61,21 @@ def _gram64(a: Tensor) -> Tensor:
     return gram
 
 
-def _kept_rank(sing: Tensor) -> Tensor:
-    """optex.py:184-185: first index whose cumulative singular-VALUE share exceeds 0.9 (a device scalar; batched over dim 0)"""
+# The kept rank k is where the cumulative singular-VALUE share crosses 0.9 (optex.py:184-185): a discontinuous function of the
+# spectrum.  When the crossing is closer than this to 0.9 the Gram route's round-off could decide k differently from the
+# reference's SVD (and k sets C for the whole layer: rotation sizes, the RNG stream consumed, everything after it), so such
+# a fit is redone with the literal torch.linalg.svd call.
+PCA_RANK_MARGIN = 2e-6
+
+
+def _kept_rank(sing: Tensor):
+    """optex.py:184-185: first index whose cumulative singular-VALUE share exceeds 0.9, and the distance of the crossing from
+    0.9 on either side (device scalars; batched over dim 0)"""
     share = torch.cumsum(sing / torch.sum(sing, dim=-1, keepdim=True), dim=-1)
-    return (share > 0.9).to(torch.int32).argmax(dim=-1)
+    k = (share > 0.9).to(torch.int32).argmax(dim=-1)
+    above = torch.gather(share, -1, k.long().unsqueeze(-1)).squeeze(-1) - 0.9
+    below = 0.9 - torch.gather(share, -1, (k.long() - 1).clamp_min(0).unsqueeze(-1)).squeeze(-1)
+    return k, torch.minimum(above, torch.where(k > 0, below, above)).to(torch.float32)
 
 
 def _check_rank(k: int) -> int:
@@ -74,28 +85,40 @@ def _check_rank(k: int) -> int:
     return k
 
 
-def fit_pca_cm(style_cm: Tensor):
+def _route(route: Optional[str]) -> str:
+    route = PCA_FIT if route is None else route
+    if route not in ("gram", "svd"):
+        raise ValueError(f"pca_fit must be 'gram' or 'svd', got {route!r}")
+    return route
+
+
+def fit_pca_cm(style_cm: Tensor, route: Optional[str] = None):
     """style_cm [B, C, n] -> (projected [B, k, n], eigvecs [C, k]).  Reference quirks kept: centring by the GLOBAL scalar
-    mean, projecting the UNCENTRED tensor, k = first index whose cumulative *singular-value* share exceeds 0.9."""
+    mean, projecting the UNCENTRED tensor, k = first index whose cumulative *singular-value* share exceeds 0.9.
+    route: "gram" / "svd" (None = the module default PCA_FIT)."""
     a = _centred(style_cm)
-    if PCA_FIT == "gram" and style_cm.is_cuda:
+    gram = _route(route) == "gram" and style_cm.is_cuda
+    if gram:
         lam, vec = torch.linalg.eigh(_gram64(a))                       # ascending eigenvalues, columns = eigenvectors
         sing = lam.clamp_min(0).sqrt().flip(0).to(torch.float32)       # singular values, descending (optex.py:183)
         vh = vec.flip(1).t().to(torch.float32)                         # rows = right singular vectors
     else:
         _, sing, vh = torch.linalg.svd(a, full_matrices=False)
-    k = _check_rank(int(_kept_rank(sing).item()))
-    eigvecs = vh[:k].t().contiguous().to(style_cm.device)  # [C, k]
+    k, margin = _kept_rank(sing)
+    k, margin = int(k.item()), float(margin.item())
+    if gram and margin < PCA_RANK_MARGIN:
+        return fit_pca_cm(style_cm, "svd")  # the rank is decided inside round-off: take the reference's own route
+    eigvecs = vh[:_check_rank(k)].t().contiguous().to(style_cm.device)  # [C, k]
     return project_cm(style_cm, eigvecs), eigvecs
 
 
-def fit_pca_many(feats: List[Tensor]):
+def fit_pca_many(feats: List[Tensor], route: Optional[str] = None):
     """fit_pca_cm for several feature sets at once (the style at every pass size and every layer of a forward call: the
     style side does not depend on the pastiche).  The symmetric eigenproblems of equal width are solved as ONE batched
     torch.linalg.eigh — 25 device calls one after the other take 187 ms for a five-layer run, rocSOLVER's batched solver
     works on them side by side — and all ranks k come back in one host transfer.  Returns [(projected, eigvecs), ...]."""
-    if not (PCA_FIT == "gram" and feats and feats[0].is_cuda):
-        return [fit_pca_cm(f) for f in feats]
+    if not (_route(route) == "gram" and feats and feats[0].is_cuda):
+        return [fit_pca_cm(f, route) for f in feats]
     by_width = {}
     for i, f in enumerate(feats):
         by_width.setdefault(int(f.shape[1]), []).append(i)
@@ -106,9 +129,13 @@ def fit_pca_many(feats: List[Tensor]):
         v_all = vec.flip(-1).transpose(-1, -2).to(torch.float32)
         for j, i in enumerate(idx):
             sing[i], vh[i] = s_all[j], v_all[j]
-    ranks = torch.stack([_kept_rank(sv) for sv in sing]).tolist()      # the one host synchronisation of all fits
+    km = [_kept_rank(sv) for sv in sing]
+    packed = torch.stack([torch.stack([k.to(torch.float32), m]) for k, m in km]).tolist()   # the one host synchronisation of all fits
     out = []
-    for f, v, k in zip(feats, vh, ranks):
+    for f, v, (k, margin) in zip(feats, vh, packed):
+        if margin < PCA_RANK_MARGIN:
+            out.append(fit_pca_cm(f, "svd"))
+            continue
         eigvecs = v[:_check_rank(int(k))].t().contiguous()
         out.append((project_cm(f, eigvecs), eigvecs))
     return out
@@ -245,13 +272,14 @@ class OptimalTexture(torch.nn.Module):
     """Same constructor arguments and defaults as the reference (optex.py:16-28) plus extensions:
     layers (VGG depths to run, deepest first; the reference hard-codes 5..1), models_dir (pretrained weights; None =
     seeded synthetic weights), allow_synthetic (depths whose .pth file is missing get synthetic weights instead of
-    raising), independent (batch = independent textures instead of one pooled distribution)."""
+    raising), independent (batch = independent textures instead of one pooled distribution), codec_layout (vgg.py), pca_fit (how fit_pca finds its basis: "gram" or the literal "svd")."""
 
     def __init__(self, size: int = 512, iters: int = 500, passes: int = 5, hist_mode: str = "chol",
                  color_transfer: Optional[str] = None, content_strength: float = 0.1, style_scale: float = 1,
                  mixing_alpha: float = 0.5, no_pca: bool = False, no_multires: bool = False,
                  layers=(5, 4, 3, 2, 1), models_dir: Optional[str] = None, independent: bool = False,
-                 fuse_rotations: bool = False, allow_synthetic: bool = False, index_by_position: bool = False):
+                 fuse_rotations: bool = False, allow_synthetic: bool = False, index_by_position: bool = False,
+                 codec_layout: Optional[str] = None, pca_fit: Optional[str] = None):
         super().__init__()
         self.hist_mode = hist_mode
         self.color_transfer = color_transfer
@@ -259,13 +287,15 @@ class OptimalTexture(torch.nn.Module):
         self.style_scale = style_scale
         self.mixing_alpha = mixing_alpha
         self.use_pca = not no_pca
+        self.pca_fit = None if pca_fit is None else _route(pca_fit)  # "gram" / "svd" (optex.py:183's literal call); None = PCA_FIT
         self.independent = independent
         self.fuse_rotations = fuse_rotations  # optional re-association (m @ R^T) @ R' -> m @ (R^T R'), cdf / sort only
         self.passes = passes
         self.iters_per_pass_and_layer, self.sizes = get_iters_and_sizes(size, iters, passes, not no_multires)
         self.layers = tuple(sorted({int(l) for l in layers}, reverse=True))
-        self.encoders = torch.nn.ModuleList([Encoder(l, models_dir, allow_synthetic) for l in self.layers])
-        self.decoders = torch.nn.ModuleList([Decoder(l, models_dir, allow_synthetic) for l in self.layers])
+        # codec_layout: memory layout of the convolutions inside the fused codec path ("mixed" / "nchw", vgg.py); None = default
+        self.encoders = torch.nn.ModuleList([Encoder(l, models_dir, allow_synthetic, codec_layout) for l in self.layers])
+        self.decoders = torch.nn.ModuleList([Decoder(l, models_dir, allow_synthetic, codec_layout) for l in self.layers])
         # The reference indexes its schedule and its content blend by the POSITION l of an encoder in its list
         # (optex.py:112-117); with its hard-coded five-encoder list position == 5 - depth, which is what a subset of
         # layers keeps by default.  index_by_position=True reproduces a reference whose list holds only `layers`.
@@ -296,7 +326,7 @@ class OptimalTexture(torch.nn.Module):
                 hws.append((int(sf.shape[2]), int(sf.shape[3])))
                 feats.append(sf.reshape(sf.shape[0], sf.shape[1], -1))
         if self.use_pca:
-            fitted = fit_pca_many(feats)
+            fitted = fit_pca_many(feats, self.pca_fit)
         else:
             fitted = [(sf, torch.empty((0, 0), device=sf.device)) for sf in feats]
         n_enc, out = len(self.encoders), []

@@ -58,13 +58,15 @@ def _synthetic_init(model: nn.Sequential, seed: int):
 # Layout policy of the fused codec path: "mixed" runs every 3x3 convolution with >= 64 output channels
 # channels-last (MIOpen's MFMA implicit-GEMM kernels: 8-20 % faster than the planar Winograd assembly at these shapes,
 # scripts/conv_layout_probe.py) and keeps the 3-channel ends and the feature hand-off to the OT kernels planar; the
-# glue pass between two convolutions changes the layout for free.  "nchw" keeps everything planar.
-CODEC_LAYOUT = os.environ.get("OPTEX_CODEC_LAYOUT", "mixed")
+# glue pass between two convolutions changes the layout for free.  "nchw" keeps everything planar.  A constructor argument
+# of Encoder / Decoder / OptimalTexture (`codec_layout`); this is only its default — nothing is read from the environment.
+CODEC_LAYOUT = "mixed"
+CODEC_LAYOUTS = ("mixed", "nchw")
 
 
-def _conv_channels_last(m: nn.Conv2d) -> bool:
+def _conv_channels_last(m: nn.Conv2d, layout: str) -> bool:
     # 64 -> 3 (the last decoder convolution) is the one wide 3x3 shape MIOpen runs faster planar (2.5 vs 3.0 ms)
-    return CODEC_LAYOUT == "mixed" and m.kernel_size == (3, 3) and m.out_channels >= 64
+    return layout == "mixed" and m.kernel_size == (3, 3) and m.out_channels >= 64
 
 
 def _weight(m: nn.Conv2d, channels_last: bool):
@@ -83,13 +85,14 @@ def _weight(m: nn.Conv2d, channels_last: bool):
     return m._optex_w_cl
 
 
-def run_fused(model: nn.Sequential, x):
+def run_fused(model: nn.Sequential, x, layout=None):
     """Run one of the Sequentials above with every convolution on MIOpen (bias-free) and everything BETWEEN two
     convolutions — bias, ReLU, max-pool / upsample, reflection pad, and the change of memory layout the next
-    convolution wants — in one pass of optex_vgg_glue_layout (csrc/glue.hip).  With CODEC_LAYOUT = "nchw" the result is
+    convolution wants — in one pass of optex_vgg_glue_layout (csrc/glue.hip).  With layout "nchw" the result is
     bit-identical to model(x) (only the kernel boundaries move); with "mixed" the convolutions run through other MIOpen
-    kernels, i.e. a different fp32 summation order inside the convolution."""
+    kernels, i.e. a different fp32 summation order inside the convolution.  layout None = the module default CODEC_LAYOUT."""
     from . import ops
+    layout = CODEC_LAYOUT if layout is None else layout
     cur, bias = x, None
     relu = pool = up = False
     pad = 0
@@ -103,7 +106,7 @@ def run_fused(model: nn.Sequential, x):
 
     for m in model:
         if isinstance(m, nn.Conv2d):
-            cl = _conv_channels_last(m)
+            cl = _conv_channels_last(m, layout)
             flush(cl)
             cur = torch.nn.functional.conv2d(cur, _weight(m, cl), None)
             bias = m.bias
@@ -127,10 +130,13 @@ def run_fused(model: nn.Sequential, x):
 class _Codec(nn.Module):
     FILE = ""
 
-    def __init__(self, depth: int, layers, models_dir=None, seed=0, allow_synthetic=False):
+    def __init__(self, depth: int, layers, models_dir=None, seed=0, allow_synthetic=False, codec_layout=None):
         super().__init__()
         assert isinstance(depth, int) and 1 <= depth <= 5
+        if codec_layout is not None and codec_layout not in CODEC_LAYOUTS:
+            raise ValueError(f"codec_layout must be one of {CODEC_LAYOUTS}, got {codec_layout!r}")
         self.depth = depth
+        self.codec_layout = codec_layout  # None = the module default (vgg.CODEC_LAYOUT) at call time
         self.model = nn.Sequential(*layers)
         path = os.path.join(models_dir, self.FILE.format(depth)) if models_dir else None
         if path and os.path.exists(path):
@@ -149,8 +155,9 @@ class _Codec(nn.Module):
 class Encoder(_Codec):
     FILE = "vgg_normalised_conv{}_1.pth"
 
-    def __init__(self, depth: int, models_dir=None, allow_synthetic=False):
-        super().__init__(depth, encoder_layers(depth), models_dir, seed=100, allow_synthetic=allow_synthetic)
+    def __init__(self, depth: int, models_dir=None, allow_synthetic=False, codec_layout=None):
+        super().__init__(depth, encoder_layers(depth), models_dir, seed=100, allow_synthetic=allow_synthetic,
+                         codec_layout=codec_layout)
 
     def out_shape(self, h: int, w: int):
         """(C, H', W') of features() for an H x W image, from the layer list alone (no convolution is run): what a rank
@@ -170,7 +177,7 @@ class Encoder(_Codec):
     def features(self, x):
         """NCHW image -> NCHW feature (channel-major per image: the layout every OT kernel wants)"""
         if x.is_cuda and not torch.is_grad_enabled():
-            return run_fused(self.model, x)
+            return run_fused(self.model, x, self.codec_layout)
         return self.model(x)
 
     def forward(self, x):
@@ -180,12 +187,13 @@ class Encoder(_Codec):
 class Decoder(_Codec):
     FILE = "feature_invertor_conv{}_1.pth"
 
-    def __init__(self, depth: int, models_dir=None, allow_synthetic=False):
-        super().__init__(depth, decoder_layers(depth), models_dir, seed=200, allow_synthetic=allow_synthetic)
+    def __init__(self, depth: int, models_dir=None, allow_synthetic=False, codec_layout=None):
+        super().__init__(depth, decoder_layers(depth), models_dir, seed=200, allow_synthetic=allow_synthetic,
+                         codec_layout=codec_layout)
 
     def decode(self, feat_nchw):
         if feat_nchw.is_cuda and not torch.is_grad_enabled():
-            return run_fused(self.model, feat_nchw)
+            return run_fused(self.model, feat_nchw, self.codec_layout)
         return self.model(feat_nchw)
 
     def forward(self, x):

@@ -309,6 +309,23 @@ def test_bench_gpus2_spawns_its_own_ranks_dry_run():
     assert d["first_timed_texture_by_rank"] == [16, 24]           # step 1 (after one warm-up step): groups 2 and 3
 
 
+def test_bench_total_is_strong_scaling_dry_run():
+    """`--total 64 --gpus 2` = BASELINE config 4's partitioning (a fixed job split evenly over the ranks): 32 textures per
+    rank per step, "scaling": "strong", the same global texture numbering; an uneven split is refused"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--total", "64", "--dry_run"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["textures_per_gpu_per_step"] == 32
+    assert d["textures_total"] == 64 * 2 and d["first_timed_texture_by_rank"] == [64, 96]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total", "9", "--dry_run"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "does not split evenly" in (r.stdout + r.stderr)
+
+
 def test_bench_refuses_a_world_that_differs_from_gpus():
     import subprocess
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
@@ -318,8 +335,9 @@ def test_bench_refuses_a_world_that_differs_from_gpus():
 
 
 def _known_shapes_job(rank, world, device):
-    """StyleSync.broadcast_known: shapes agreed in advance, one message; a source whose tensors do not fit raises — after
-    the collective, so the receiver is not left waiting (it gets the marked payload and carries on to ITS next collective)"""
+    """StyleSync.broadcast_known: shapes agreed in advance, one message; a source whose tensors do not fit marks the payload
+    and EVERY rank raises — after the collective, so nobody is left waiting in it (the receiver used to carry
+    on with a NaN payload)"""
     sync = otdist.StyleSync(device)
     g = torch.Generator().manual_seed(3)
     shapes = [(1, 8, 24), (2, 5), (0, 0)]
@@ -337,7 +355,7 @@ def _known_shapes_job(rank, world, device):
 def test_style_sync_known_shapes_single_message_gloo_world2():
     res = run_world(_known_shapes_job, 2)
     (a, ma, ra, aa), (b, mb, rb, ab) = res[0], res[1]
-    assert ma == mb == 3 and ra and not rb and aa == ab == [1.5] * 4
+    assert ma == mb == 3 and ra and rb and aa == ab == [1.5] * 4
     for x, y in zip(a, b):
         assert x.shape == y.shape and np.array_equal(x, y)
     assert a[2].shape == (0, 0)

@@ -825,6 +825,38 @@ def test_per_texture_rotation_streams_equal_separate_runs(dev, mode, S, C, n, ns
     assert biteq(shared.cpu().numpy()[0], batch[0]) and not biteq(shared.cpu().numpy()[1], batch[1])
 
 
+@pytest.mark.parametrize("mode,C,blend", [("cdf", 256, False), ("sort", 256, False), ("chol", 256, True), ("sym", 64, False),
+                                           ("pca", 181, False), ("cdf", 181, True)])
+def test_ot_loop_is_hipgraph_capturable(dev, mode, C, blend):
+    """include/optex.h promises stream-ordered, hipGraph-capturable calls: a whole (pass, layer)
+    optex_ot_loop is captured with torch.cuda.graph (nothing runs during capture), replayed, and gives the eager call's
+    bits; replayed again on restored inputs it gives them again (no state left behind in the scratch)."""
+    from optimaltextures_amd import ops
+    S, n, ns, iters = 4, 4096, 3072, 3
+    rng = np.random.default_rng(C + len(mode))
+    x0 = cu(relu_feat(rng, S, C, n, scale=2.0, shift=0.3), dev)
+    sty = cu(relu_feat(rng, 1, C, ns, scale=1.5, shift=0.5), dev)
+    content = cu(relu_feat(rng, S, C, n, scale=2.0), dev) if blend else None
+    lr = orc.LegacyRNG(C + 1)
+    R = np.stack([orc.random_rotation(C, lr) for _ in range(iters)]).astype(np.float32)
+    Rd, Rtd = cu(R, dev), cu(np.ascontiguousarray(R.transpose(0, 2, 1)), dev)
+    kw = dict(content=content, strength=0.05 if blend else 0.0)
+    eager = x0.clone()
+    ops.ot_loop(mode, eager, sty, Rd, Rtd, **kw)
+    torch.cuda.synchronize()
+    static_x = x0.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.ot_loop(mode, static_x, sty, Rd, Rtd, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(static_x, x0), "capture must not execute anything"
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_x, eager), f"{mode}: the replayed graph differs from the eager call"
+        static_x.copy_(x0)
+
+
 # ================================================================================================ full-size (BASELINE) properties
 def test_full_size_relu3_1_step_vs_oracle(dev):
     """BASELINE config shape: relu3_1 at the 512 pass, C = 256, n = 128*128, style 128x96 — one whole cdf step bit-exact
@@ -918,25 +950,21 @@ def test_vgg_glue_matches_torch_modules_bit_exact(dev, N, C, H, W, relu, pool, u
 def test_vgg_codec_fused_path_equals_module_path(dev, depth):
     """Encoder.features / Decoder.decode through the fused glue == the plain nn.Sequential on the same device, in both
     layout policies ("mixed": the wide convolutions run channels-last through other MIOpen kernels)"""
-    from optimaltextures_amd import vgg
     from optimaltextures_amd.vgg import Decoder, Encoder
-    enc, dec = Encoder(depth).to(dev).eval(), Decoder(depth).to(dev).eval()
     x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(depth)).to(dev)
-    saved = vgg.CODEC_LAYOUT
-    try:
-        for layout, tol in (("nchw", 1e-5), ("mixed", 5e-5)):
-            vgg.CODEC_LAYOUT = layout
-            with torch.inference_mode():
-                f_fused, f_plain = enc.features(x), enc.model(x)
-                # bias-free conv + our add vs MIOpen's own bias handling (and, for "mixed", another convolution kernel):
-                # fp32 summation-order noise only
-                assert f_fused.is_contiguous() and f_fused.shape == f_plain.shape
-                assert torch.allclose(f_fused, f_plain, rtol=0, atol=tol * float(f_plain.abs().max())), layout
-                d_fused, d_plain = dec.decode(f_plain), dec.model(f_plain)
-                assert d_fused.shape == d_plain.shape == x.shape and d_fused.is_contiguous()
-                assert torch.allclose(d_fused, d_plain, rtol=0, atol=tol * float(d_plain.abs().max())), layout
-    finally:
-        vgg.CODEC_LAYOUT = saved
+    for layout, tol in (("nchw", 1e-5), ("mixed", 5e-5), (None, 5e-5)):   # None = the module default ("mixed")
+        enc, dec = Encoder(depth, codec_layout=layout).to(dev).eval(), Decoder(depth, codec_layout=layout).to(dev).eval()
+        with torch.inference_mode():
+            f_fused, f_plain = enc.features(x), enc.model(x)
+            # bias-free conv + our add vs MIOpen's own bias handling (and, for "mixed", another convolution kernel):
+            # fp32 summation-order noise only
+            assert f_fused.is_contiguous() and f_fused.shape == f_plain.shape
+            assert torch.allclose(f_fused, f_plain, rtol=0, atol=tol * float(f_plain.abs().max())), layout
+            d_fused, d_plain = dec.decode(f_plain), dec.model(f_plain)
+            assert d_fused.shape == d_plain.shape == x.shape and d_fused.is_contiguous()
+            assert torch.allclose(d_fused, d_plain, rtol=0, atol=tol * float(d_plain.abs().max())), layout
+    with pytest.raises(ValueError):
+        Encoder(depth, codec_layout="nhwc")
 
 
 # ================================================================================================ N1 / N2 "next" rows

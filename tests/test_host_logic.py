@@ -58,6 +58,52 @@ def test_cli_keeps_every_reference_flag():
     assert b.style == ["a.jpg", "b.jpg"] and b.content == "c.jpg" and b.hist_mode == "cdf" and b.no_pca
 
 
+def test_cli_extension_flags_and_constructor_arguments():
+    """--pca_fit / --codec_layout (the literal SVD route stays selectable for parity runs; VERDICT r3 item 9: the
+    codec layout is a constructor argument, not an environment variable)"""
+    import optex as cli
+    from optimaltextures_amd import vgg
+    from optimaltextures_amd.driver import OptimalTexture
+    a = cli.build_parser().parse_args([])
+    assert a.pca_fit == "gram" and a.codec_layout == "mixed"
+    b = cli.build_parser().parse_args(["--pca_fit", "svd", "--codec_layout", "nchw"])
+    assert b.pca_fit == "svd" and b.codec_layout == "nchw"
+    with pytest.raises(SystemExit):
+        cli.build_parser().parse_args(["--pca_fit", "qr"])
+    t = OptimalTexture(size=256, layers=(1,), codec_layout="nchw", pca_fit="svd")
+    assert t.pca_fit == "svd" and t.encoders[0].codec_layout == "nchw" and t.decoders[0].codec_layout == "nchw"
+    with pytest.raises(ValueError):
+        OptimalTexture(size=256, layers=(1,), pca_fit="qr")
+    with pytest.raises(ValueError):
+        OptimalTexture(size=256, layers=(1,), codec_layout="nhwc")
+    import inspect
+    assert "os.environ" not in inspect.getsource(vgg) and "getenv" not in inspect.getsource(vgg)
+
+
+def test_kept_rank_rule_and_margin():
+    """optex.py:184-185: k = index of the first cumulative singular-value share ABOVE 0.9 (SURVEY 8f N1's known answer:
+    shares [0.54, 0.808, 0.912, ...] keep k = 2), and the distance of that crossing from 0.9, which decides whether the Gram
+    route's k can be trusted (driver.PCA_RANK_MARGIN)"""
+    import torch
+    from optimaltextures_amd import driver
+    sing = torch.tensor([0.54, 0.268, 0.104, 0.05, 0.038])
+    k, margin = driver._kept_rank(sing)
+    assert int(k) == 2 and abs(float(margin) - 0.012) < 1e-6
+    # a crossing inside round-off of 0.9: the margin says so
+    sing = torch.tensor([0.5, 0.4 + 5e-7, 0.1 - 5e-7])
+    k, margin = driver._kept_rank(sing)
+    assert float(margin) < driver.PCA_RANK_MARGIN
+    # batched, and the CPU route of fit_pca_cm is the literal SVD with the same rule
+    k, margin = driver._kept_rank(torch.tensor([[0.54, 0.268, 0.104, 0.088], [0.95, 0.03, 0.01, 0.01]]))
+    assert k.tolist() == [2, 0] and float(margin[1]) > 0.04
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 6, 500, generator=g) * torch.tensor([5.0, 3.0, 1.0, 0.5, 0.2, 0.1]).view(1, 6, 1)
+    a = x.permute(0, 2, 1).reshape(-1, 6) - x.mean()
+    sv = torch.linalg.svdvals(a)
+    want_k = int((torch.cumsum(sv / sv.sum(), 0) > 0.9).to(torch.int32).argmax())
+    assert int(driver._kept_rank(sv)[0]) == want_k
+
+
 def test_hls_conversion_matches_colorsys_and_round_trips():
     """driver.rgb_to_hls / hls_to_rgb stand in for kornia.color.hls (optex.py:126-131; kornia is not installed):
     h in radians [0, 2pi), channel order (h, l, s) like kornia."""
