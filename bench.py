@@ -219,6 +219,9 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timing", action="store_true", help="do not record HIP events in the timed steps")
     ap.add_argument("--no_miopen_find", action="store_true", help="torch.backends.cudnn.benchmark = False: MIOpen picks the convolution kernels from its heuristics / find-db instead of timing every solver in the warm-up step")
+    ap.add_argument("--host_rng", action="store_true",
+                    help="draw the rotations' normals from numpy on the host and upload them (the round-1..3 path) instead of "
+                         "advancing the same numpy streams on the GPU (rotation.DeviceNormals, optex_legacy_normals)")
     ap.add_argument("--seed", type=int, default=0, help="job seed: texture i's noise and its rotation group's sequence are functions of (seed, i) only (dist.py)")
     ap.add_argument("--dry_run", action="store_true",
                     help="no GPU work: join the process group (gloo on CPU), walk the steps' texture shards, exercise the "
@@ -262,10 +265,16 @@ def main():
     # whatever the number of GPUs.
     counter = {"step": 0}
 
+    def rot(groups):
+        """the rotation stream(s) of the dist.py seeding rule: advanced on the GPU by default, on the host with --host_rng"""
+        if not args.host_rng:
+            return otdist.rotation_stream(args.seed, groups, device)
+        return [otdist.rotation_rng(args.seed, g) for g in groups] if isinstance(groups, list) else otdist.rotation_rng(args.seed, groups)
+
     def step(model):
         q = counter["step"] * world + rank
         counter["step"] += 1
-        model.rng = otdist.rotation_rng(args.seed, q)
+        model.rng = rot(q)
         pastiche = otdist.texture_noise(q * B, B, (3, SIZE, SIZE), device, seed=args.seed)
         return model.forward(pastiche, [style])
 
@@ -307,7 +316,9 @@ def main():
                                f"5 passes 256..512, 52 OT iterations (default iters=500), hist_mode={args.hist_mode}, "
                                "style 736x512 synthetic, random-init VGG weights",
                    "textures_per_gpu_per_step": B, "hist_mode": args.hist_mode, "parallelism": f"textures x{world}",
-                   "rotation_sharing": f"one sequence per rotation group of {B} textures (= one rank's step), seeded by the group's global number"},
+                   "rotation_sharing": f"one sequence per rotation group of {B} textures (= one rank's step), seeded by the group's global number",
+                   "rotation_stream": "numpy RandomState gaussian stream, drawn on the host" if args.host_rng else
+                                      "numpy RandomState gaussian stream advanced on the GPU (optex_legacy_normals)"},
     }
     traffic, traffic_source = pmc_traffic()
     if traffic_source:
@@ -366,7 +377,7 @@ def main():
                 def step8():
                     q = counter["step"]
                     counter["step"] += 1
-                    tex.rng = otdist.rotation_rng(args.seed, q)
+                    tex.rng = rot(q)
                     return tex.forward(otdist.texture_noise(q * 8, 8, (3, SIZE, SIZE), device, seed=args.seed), [style])
 
                 for _ in range(2):
@@ -433,7 +444,7 @@ def main():
                 def own_step():
                     q = counter["step"]
                     counter["step"] += 1
-                    m.rng = [otdist.rotation_rng(args.seed, q * B + j) for j in range(B)]
+                    m.rng = rot([q * B + j for j in range(B)])
                     return m.forward(otdist.texture_noise(q * B, B, (3, SIZE, SIZE), device, seed=args.seed), [style])
 
                 own_step()
@@ -443,7 +454,9 @@ def main():
                 torch.cuda.synchronize()
                 result["textures_per_s_independent_rotations"] = {
                     "value": round(B / (time.perf_counter() - t0), 3),
-                    "config": f"hist_mode={args.hist_mode}, one rotation sequence per texture (rotation group size 1), host threads for the numpy streams: {min(64, os.cpu_count() or 1)}"}
+                    "config": f"hist_mode={args.hist_mode}, one rotation sequence per texture (rotation group size 1), " +
+                              (f"numpy streams on {min(64, os.cpu_count() or 1)} host threads" if args.host_rng else
+                               f"{B} numpy streams advanced on the GPU side by side")}
         if "single" in args.other_modes.split(","):
             # latency of ONE texture with the reference's default command line (`python optex.py`: B = 1, all five layers,
             # PCA, hist_mode chol, 500 iterations, 512^2; BASELINE config 2 with chol): launch-bound, not a throughput number
@@ -451,7 +464,7 @@ def main():
                 m = OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode="chol", layers=(5, 4, 3, 2, 1)).to(device).eval()
                 lat = []
                 for rep in range(3):
-                    m.rng = otdist.rotation_rng(args.seed, 10 ** 6 + rep)
+                    m.rng = rot(10 ** 6 + rep)
                     noise = otdist.texture_noise(10 ** 6 + rep, 1, (3, SIZE, SIZE), device, seed=args.seed)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
@@ -487,7 +500,7 @@ def main():
                     m = OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode=mode, no_pca=True, layers=(LAYER,),
                                        independent=True, models_dir=models).to(device).eval()
                     for timed in (False, True):
-                        m.rng = otdist.rotation_rng(args.seed, counter["step"])
+                        m.rng = rot(counter["step"])
                         pastiche = otdist.texture_noise(counter["step"] * B, B, (3, SIZE, SIZE), device, seed=args.seed)
                         counter["step"] += 1
                         torch.cuda.synchronize()

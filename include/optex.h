@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 6
+#define OPTEX_ABI_VERSION 7
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -159,6 +159,14 @@ int optex_transfer_operator(int mode, const float* cov_t, const float* cov_s, in
  * ------------------------------------------------------------------------------------------------- */
 long optex_rotation_normals(int N);
 size_t optex_rotation_ws_bytes(int N, int count);
+/* The stream itself on the device (ABI 7): numpy's RandomState.normal — MT19937 + the legacy polar method with its one-value
+ * cache, what scipy's rvs draws from (optex.py:149) — advanced from / to a state of optex_mt19937_state_bytes() bytes per
+ * stream: uint32 key[624], uint32 pos, uint32 has_gauss, double cached_gaussian = RandomState.get_state()[1:5].  `states`
+ * holds n_streams of them back to back and is updated in place; stream s writes its next `count` values to
+ * out + s * out_stride (out_stride >= count).  One workgroup per stream.  Every operation is the host's IEEE operation
+ * except log(): a value equals numpy's bit for bit or differs by one unit in the last place of the double. */
+size_t optex_mt19937_state_bytes(void);
+int optex_legacy_normals(void* states, int n_streams, long count, double* out, long out_stride, void* stream);
 int optex_rotations_from_normals(const double* normals, int N, int count, double* R64, float* R32, float* Rt32,
                                  void* ws, size_t ws_bytes, void* stream);
 

@@ -7,7 +7,7 @@ import torch  # imported BEFORE the CDLL so the library binds to the HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liboptex_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 CHANNEL_MAJOR, PIXEL_MAJOR = 0, 1
 
 _c = ctypes
@@ -40,6 +40,8 @@ SIGNATURES = {
     "optex_transfer_operator": (_I, [_I, _P, _P, _I, _I, _I, _F, _P, _P, _SZ, _P]),
     "optex_rotation_normals": (_L, [_I]),
     "optex_rotation_ws_bytes": (_SZ, [_I, _I]),
+    "optex_mt19937_state_bytes": (_SZ, []),
+    "optex_legacy_normals": (_I, [_P, _I, _L, _P, _L, _P]),
     "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "optex_ot_loop_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I, _L]),
     "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _L, _I, _P, _F, _I, _P, _SZ, _P]),

@@ -45,6 +45,41 @@ int device_cu_count() {
     return cached_cu;
 }
 
+// ---------------------------------------------------------------------------------------------- copies and fills as kernels
+__global__ __launch_bounds__(256) void copy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t count, int vec) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const size_t q = count / 4;
+        for (size_t i = i0; i < q; i += stride) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (size_t i = 4 * q + i0; i < count; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = i0; i < count; i += stride) dst[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ dst, uint32_t value, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = value;
+}
+
+int device_copy(float* dst, const float* src, size_t count, hipStream_t st) {
+    if (count == 0 || dst == src) return OPTEX_OK;
+    const int vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 ? 1 : 0;
+    const size_t work = vec ? (count + 3) / 4 : count;
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, src, count, vec);
+    return check_launch("copy_kernel");
+}
+
+int device_fill_u32(uint32_t* dst, uint32_t value, size_t count, hipStream_t st) {
+    if (count == 0) return OPTEX_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, value, count);
+    return check_launch("fill_u32_kernel");
+}
+
 // ---------------------------------------------------------------------------------------------- profiler
 struct ProfState {
     bool on = false;

@@ -207,78 +207,198 @@ __global__ __launch_bounds__(256) void col_hist_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ K2c CDFs -> LUT
-// one 256-thread block per column, thread i = bin i.  lut[col] = { bin_edges[256], remapped_cdf[256], slope[256] }
-__global__ __launch_bounds__(256) void cdf_lut_kernel(const unsigned* __restrict__ hist_t,
-                                                      const unsigned* __restrict__ hist_s,
-                                                      const float* __restrict__ lo_, const float* __restrict__ hi_,
-                                                      float* __restrict__ lut, float* __restrict__ dbg) {
-    const int col = blockIdx.x, i = threadIdx.x;
-    __shared__ unsigned ct[kBins], cs[kBins];
-    __shared__ float tcdf[kBins], scdf[kBins], edges[kBins], rm[kBins];
-    const unsigned ht = hist_t[(size_t)col * kBins + i], hs = hist_s[(size_t)col * kBins + i];
-    ct[i] = ht;
-    cs[i] = hs;
+// 256 threads, thread i = bin i.  lut[col] = { bin_edges[256], remapped_cdf[256], slope[256] }
+struct LutShared {
+    unsigned ct[kBins], cs[kBins], rt[kBins], rs[kBins];
+    float tcdf[kBins], scdf[kBins], edges[kBins], rm[kBins];
+};
+
+// histmatch.py:59-67 for one column: ht / hs = the two counts of bin i = threadIdx.x; l = the column's LUT; d = NULL or the
+// column's debug record.  All 256 threads of the block call it.
+__device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned hs, float lo, float hi, float* __restrict__ l,
+                                           float* __restrict__ d) {
+    const int i = threadIdx.x;
+    S.ct[i] = ht;
+    S.cs[i] = hs;
+    S.rt[i] = ht;
+    S.rs[i] = hs;
     __syncthreads();
     // inclusive scan (Hillis-Steele); integer, hence exact and equal to torch's fp32 cumsum while totals < 2^24
     for (int off = 1; off < kBins; off <<= 1) {
-        const unsigned a = (i >= off) ? ct[i - off] : 0u, b = (i >= off) ? cs[i - off] : 0u;
+        const unsigned a = (i >= off) ? S.ct[i - off] : 0u, b = (i >= off) ? S.cs[i - off] : 0u;
         __syncthreads();
-        ct[i] += a;
-        cs[i] += b;
+        S.ct[i] += a;
+        S.cs[i] += b;
         __syncthreads();
     }
-    float ft = (float)ct[i], fs = (float)cs[i];
-    float tl = (float)ct[kBins - 1], sl = (float)cs[kBins - 1];
-    if (ct[kBins - 1] >= (1u << 24) || cs[kBins - 1] >= (1u << 24)) {
+    float ft = (float)S.ct[i], fs = (float)S.cs[i];
+    float tl = (float)S.ct[kBins - 1], sl = (float)S.cs[kBins - 1];
+    if (S.ct[kBins - 1] >= (1u << 24) || S.cs[kBins - 1] >= (1u << 24)) {
         // beyond 2^24 the reference's sequential fp32 cumsum rounds: replay it literally
         __syncthreads();
         if (i == 0) {
             float a = 0.f, b = 0.f;
             for (int k = 0; k < kBins; k++) {
-                const unsigned hk = hist_t[(size_t)col * kBins + k], sk = hist_s[(size_t)col * kBins + k];
-                a = a + (float)hk;
-                b = b + (float)sk;
-                tcdf[k] = a;
-                scdf[k] = b;
+                a = a + (float)S.rt[k];
+                b = b + (float)S.rs[k];
+                S.tcdf[k] = a;
+                S.scdf[k] = b;
             }
         }
         __syncthreads();
-        ft = tcdf[i];
-        fs = scdf[i];
-        tl = tcdf[kBins - 1];
-        sl = scdf[kBins - 1];
+        ft = S.tcdf[i];
+        fs = S.scdf[i];
+        tl = S.tcdf[kBins - 1];
+        sl = S.scdf[kBins - 1];
         __syncthreads();
     }
-    const float lo = lo_[col], hi = hi_[col];
     const float step = __fdiv_rn(hi - lo, (float)kBins);
-    tcdf[i] = __fdiv_rn(ft, tl);
-    scdf[i] = __fdiv_rn(fs, sl);
-    edges[i] = linspace_edge(lo, hi, step, i + 1);
+    S.tcdf[i] = __fdiv_rn(ft, tl);
+    S.scdf[i] = __fdiv_rn(fs, sl);
+    S.edges[i] = linspace_edge(lo, hi, step, i + 1);
     __syncthreads();
     // remapped_cdf = interp(target_cdf, source_cdf, bin_edges)   histmatch.py:67
-    const float x = tcdf[i];
-    int idx = lower_bound_f(scdf, kBins, x);
+    const float x = S.tcdf[i];
+    int idx = lower_bound_f(S.scdf, kBins, x);
     idx = idx > kBins - 1 ? kBins - 1 : idx;
-    const float r = interp_eval(x, idx, scdf, edges, kBins);
-    rm[i] = r;
+    const float r = interp_eval(x, idx, S.scdf, S.edges, kBins);
+    S.rm[i] = r;
     __syncthreads();
     const int nxt = (i + 1 > kBins - 1) ? kBins - 1 : i + 1;
-    const float slope = __fdiv_rn(rm[nxt] - rm[i], edges[nxt] - edges[i]);
-    float* l = lut + (size_t)col * 3 * kBins;
-    l[i] = edges[i];
+    const float slope = __fdiv_rn(S.rm[nxt] - S.rm[i], S.edges[nxt] - S.edges[i]);
+    l[i] = S.edges[i];
     l[kBins + i] = r;
     l[2 * kBins + i] = slope;
-    if (dbg) {
-        float* d = dbg + (size_t)col * (2 + 4 * kBins);
+    if (d) {
         if (i == 0) {
             d[0] = lo;
             d[1] = hi;
         }
         d[2 + i] = (float)ht;
         d[2 + kBins + i] = (float)hs;
-        d[2 + 2 * kBins + i] = edges[i];
+        d[2 + 2 * kBins + i] = S.edges[i];
         d[2 + 3 * kBins + i] = r;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ K2a + K2b + K2c in one launch
+// The joint range, both histograms and the LUT of every column in ONE launch (an OT iteration at 8 textures per step is
+// launch-bound: range, two histograms with their clears and the LUT were seven launches of 5-30 us each):
+//   grid = (columns, chunks_t + chunks_s): block (col, y) bins one chunk of the target (y < chunks_t) or of the source column.
+//   * range: every block folds the column's min / max itself — from the per-tile partials the rotation GEMM's epilogue left
+//     (pmn / pmx) joined with the source's range (smn / smx), or reads the joint range somebody computed (lo / hi);
+//     min / max do not depend on the order, so every block of a column gets the same bits;
+//   * counts go to the global histograms with integer atomics (exact in any order);
+//   * the LAST block of a column to finish (a counter per column) reads both histograms back through L2 and computes the
+//     LUT (lut_column), stores lo / hi for the apply kernel, and leaves the histograms and the counter ZERO for the next
+//     launch: the scratch is cleared once per call, not once per iteration.
+struct HistLutArgs {
+    const float* t; long ldt, tss, nt;
+    const float* s; long lds, sss, ns; int src_n_seg;
+    int C; long chunk_t; int chunks_t; long chunk_s; int chunks_s;
+    const float* pmn; const float* pmx; int parts;     // target min / max partials [n_seg][parts][C], or NULL:
+    const float* smn; const float* smx;                // source min / max [src_n_seg, C] (joined with the partials)
+    float* lo; float* hi;                              // joint range [ncols]: read if pmn == NULL, written by the last block
+    unsigned* ht; unsigned* hs; unsigned* done;        // zero on entry, zero on exit
+    float* lut; float* dbg;
+    int vec_t, vec_s;
+};
+
+__global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
+    const int col = blockIdx.x, seg = col / a.C, c = col % a.C, tid = threadIdx.x;
+    const bool is_t = (int)blockIdx.y < a.chunks_t;
+    __shared__ unsigned sh[4][kBins];
+    __shared__ float slo[4], shi[4];
+    __shared__ unsigned s_last;
+    __shared__ LutShared S;
+    for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
+    float lo, hi;
+    if (a.pmn) {
+        lo = INFINITY;
+        hi = -INFINITY;
+        const float* pa = a.pmn + (size_t)seg * a.parts * a.C + c;
+        const float* pb = a.pmx + (size_t)seg * a.parts * a.C + c;
+        for (int p = tid; p < a.parts; p += 256) {
+            lo = fminf(lo, pa[(size_t)p * a.C]);
+            hi = fmaxf(hi, pb[(size_t)p * a.C]);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if ((tid & 63) == 0) {
+            slo[tid >> 6] = lo;
+            shi[tid >> 6] = hi;
+        }
+        __syncthreads();
+        const int oc = ((a.src_n_seg == 1) ? 0 : seg) * a.C + c;
+        lo = fminf(fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), a.smn[oc]);   // histmatch.py:52-53
+        hi = fmaxf(fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3])), a.smx[oc]);
+    } else {
+        lo = a.lo[col];
+        hi = a.hi[col];
+        __syncthreads();
+    }
+    float hl = lo, hu = hi;
+    if (hl == hu) {  // torch.histc widens an empty range
+        hl -= 1.0f;
+        hu += 1.0f;
+    }
+    const float range = hu - hl;
+    {
+        unsigned* h = sh[tid >> 6];
+        const float* p;
+        long beg, end;
+        int vec;
+        if (is_t) {
+            p = a.t + (size_t)seg * a.tss + (size_t)c * a.ldt;
+            beg = (long)blockIdx.y * a.chunk_t;
+            end = (beg + a.chunk_t < a.nt) ? beg + a.chunk_t : a.nt;
+            vec = a.vec_t;
+        } else {
+            p = a.s + (size_t)((a.src_n_seg == 1) ? 0 : seg) * a.sss + (size_t)c * a.lds;
+            beg = (long)((int)blockIdx.y - a.chunks_t) * a.chunk_s;
+            end = (beg + a.chunk_s < a.ns) ? beg + a.chunk_s : a.ns;
+            vec = a.vec_s;
+        }
+        if (vec) {
+            const long nv = (end - beg) / 4;
+            const float4* p4 = reinterpret_cast<const float4*>(p + beg);
+            for (long i = tid; i < nv; i += 256) {
+                const float4 v = p4[i];
+                hist_add(h, v.x, hl, hu, range);
+                hist_add(h, v.y, hl, hu, range);
+                hist_add(h, v.z, hl, hu, range);
+                hist_add(h, v.w, hl, hu, range);
+            }
+            for (long i = beg + nv * 4 + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
+        } else {
+            for (long i = beg + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
+        }
+    }
+    __syncthreads();
+    {
+        unsigned* g = (is_t ? a.ht : a.hs) + (size_t)col * kBins;
+        const unsigned v = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+        if (v) atomicAdd(&g[tid], v);
+    }
+    __threadfence();   // this block's counts are visible device-wide before its ticket is
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&a.done[col], 1u) == (unsigned)(a.chunks_t + a.chunks_s - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // both histograms are complete: read them where the atomics landed (L2), leave zeros behind
+    unsigned* gt = a.ht + (size_t)col * kBins + tid;
+    unsigned* gs = a.hs + (size_t)col * kBins + tid;
+    const unsigned ht = __hip_atomic_load(gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned hs = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *gt = 0u;
+    *gs = 0u;
+    if (tid == 0) {
+        a.done[col] = 0u;
+        a.lo[col] = lo;
+        a.hi[col] = hi;
+    }
+    lut_column(S, ht, hs, lo, hi, a.lut + (size_t)col * 3 * kBins, a.dbg ? a.dbg + (size_t)col * (2 + 4 * kBins) : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ K3 apply
@@ -529,11 +649,7 @@ static int launch_hist(const float* x, long ld, long ss, long n, int C, int x_n_
     long chunk = pick_chunk(n, ncols, device_cu_count());
     const int chunks = (int)((n + chunk - 1) / chunk);
     if (chunks > 1) {
-        hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)ncols * kBins, st);
-        if (e != hipSuccess) {
-            set_error("col_hist: memset failed: %s", hipGetErrorString(e));
-            return OPTEX_E_LAUNCH;
-        }
+        if (int rc = device_fill_u32(hist, 0u, (size_t)ncols * kBins, st)) return rc;
     }
     // algorithmic bytes: every DISTINCT column once — a shared source (x_n_seg == 1) is binned with each target segment's
     // range (n_seg blocks per channel re-read it through L2) but comes from HBM once
@@ -547,11 +663,13 @@ static int launch_hist(const float* x, long ld, long ss, long n, int C, int x_n_
 struct CdfWs {
     float *smn, *smx;   // source min/max          [src_n_seg <= n_seg, C]
     float *lo, *hi;     // joint range             [n_seg, C]
-    unsigned *ht, *hs;  // histograms              [n_seg, C, 256]
+    unsigned *ht, *hs;  // histograms              [n_seg, C, 256]   } zero between launches of cdf_hist_lut_kernel
+    unsigned* done;     // finished blocks         [n_seg, C]        }
     float* lut;         // edges, remapped, slope  [n_seg, C, 3, 256]
+    size_t clear_words; // ht, hs and done are contiguous: one fill clears them
     static size_t bytes(int C, int n_seg) {
         const size_t cols = (size_t)C * n_seg;
-        return align_up(cols * 4 * sizeof(float), 256) + align_up(cols * 2 * kBins * sizeof(unsigned), 256) +
+        return align_up(cols * 4 * sizeof(float), 256) + align_up(cols * (2 * kBins + 1) * sizeof(unsigned), 256) +
                align_up(cols * 3 * kBins * sizeof(float), 256);
     }
     CdfWs(void* ws, int C, int n_seg) {
@@ -564,10 +682,21 @@ struct CdfWs {
         p += align_up(cols * 4 * sizeof(float), 256);
         ht = reinterpret_cast<unsigned*>(p);
         hs = ht + cols * kBins;
-        p += align_up(cols * 2 * kBins * sizeof(unsigned), 256);
+        done = hs + cols * kBins;
+        clear_words = cols * (2 * kBins + 1);
+        p += align_up(cols * (2 * kBins + 1) * sizeof(unsigned), 256);
         lut = reinterpret_cast<float*>(p);
     }
 };
+
+int cdf_ws_clear(void* ws, int C, int n_seg, hipStream_t st) {
+    CdfWs w(ws, C, n_seg);
+    return device_fill_u32(w.ht, 0u, w.clear_words, st);
+}
+
+int col_minmax_launch(const float* x, long ld, long ss, long n, int C, int n_seg, float* mn, float* mx, hipStream_t st) {
+    return launch_minmax(x, ld, ss, n, C, n_seg, nullptr, nullptr, 1, mn, mx, st);
+}
 
 int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
@@ -576,38 +705,61 @@ int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float
                                 nullptr, nullptr, 0, st);
 }
 
-// tmn_parts / tmx_parts [n_seg][parts][C]: per-tile min / max of the target the producing GEMM already took (or NULL)
+// tmn_parts / tmx_parts [n_seg][parts][C]: per-tile min / max of the target the producing GEMM already took (or NULL);
+// smn_given / smx_given [src_n_seg, C]: the source's min / max when the caller has them (optex_ot_loop takes them for all
+// iterations of a call in one launch), else they are taken here; ws_clean: the caller cleared the scratch's counters
+// (cdf_ws_clear) — the pipeline leaves them clear, so a loop clears them once.
 int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                          int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
-                         const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st) {
+                         const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st, const float* smn_given,
+                         const float* smx_given, bool ws_clean) {
     CdfWs w(ws, C, n_seg);
+    const int ncols = C * n_seg, n_cu = device_cu_count();
     int rc;
-    if ((rc = launch_minmax(source, lds, sss, ns, C, src_n_seg, nullptr, nullptr, 1, w.smn, w.smx, st))) return rc;
-    if (tmn_parts) {
-        const int ncols = C * n_seg;
-        // reads the partials (parts / n of the map's bytes) instead of the map
-        ProfScope prof(KC_MINMAX, st, 0.0, 8.0 * (double)parts * ncols);
-        hipLaunchKernelGGL(minmax_from_parts_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, tmn_parts, tmx_parts, parts, C,
-                           ncols, w.smn, w.smx, src_n_seg, w.lo, w.hi);
-        if ((rc = check_launch("minmax_from_parts_kernel"))) return rc;
-    } else if ((rc = launch_minmax(target, ldt, tss, nt, C, n_seg, w.smn, w.smx, src_n_seg, w.lo, w.hi, st))) {
-        return rc;
+    if (!ws_clean && (rc = device_fill_u32(w.ht, 0u, w.clear_words, st))) return rc;
+    const float *smn = smn_given, *smx = smx_given;
+    if (!smn || !smx) {
+        if ((rc = launch_minmax(source, lds, sss, ns, C, src_n_seg, nullptr, nullptr, 1, w.smn, w.smx, st))) return rc;
+        smn = w.smn;
+        smx = w.smx;
     }
-    if ((rc = launch_hist(target, ldt, tss, nt, C, n_seg, n_seg, w.lo, w.hi, w.ht, st))) return rc;
-    if ((rc = launch_hist(source, lds, sss, ns, C, src_n_seg, n_seg, w.lo, w.hi, w.hs, st))) return rc;
-    const int ncols = C * n_seg;
+    if (!tmn_parts) {  // no partials: the joint range from a pass over the target (histmatch.py:52-53)
+        if ((rc = launch_minmax(target, ldt, tss, nt, C, n_seg, smn, smx, src_n_seg, w.lo, w.hi, st))) return rc;
+    }
+    HistLutArgs a;
+    a.t = target; a.ldt = ldt; a.tss = tss; a.nt = nt;
+    a.s = source; a.lds = lds; a.sss = sss; a.ns = ns; a.src_n_seg = src_n_seg;
+    a.C = C;
+    a.chunk_t = pick_chunk(nt, ncols, n_cu);
+    a.chunks_t = (int)((nt + a.chunk_t - 1) / a.chunk_t);
+    a.chunk_s = pick_chunk(ns, ncols, n_cu);
+    a.chunks_s = (int)((ns + a.chunk_s - 1) / a.chunk_s);
+    a.pmn = tmn_parts; a.pmx = tmn_parts ? tmx_parts : nullptr; a.parts = parts;
+    a.smn = smn; a.smx = smx;
+    a.lo = w.lo; a.hi = w.hi; a.ht = w.ht; a.hs = w.hs; a.done = w.done; a.lut = w.lut; a.dbg = dbg;
+    a.vec_t = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0;
+    a.vec_s = aligned16(source) && lds % 4 == 0 && sss % 4 == 0;
     {
-        ProfScope prof(KC_LUT, st, 0.0, (2.0 * 4 + 3.0 * 4) * kBins * ncols);
-        hipLaunchKernelGGL(cdf_lut_kernel, dim3(ncols), dim3(256), 0, st, w.ht, w.hs, w.lo, w.hi, w.lut, dbg);
+        // algorithmic bytes: every DISTINCT column once — a shared source (src_n_seg == 1) is binned with each target
+        // segment's range (n_seg blocks per channel re-read it through L2) but comes from HBM once; + the LUT's tables
+        ProfScope prof(KC_HIST, st, 0.0, 4.0 * ((double)nt * ncols + (double)ns * C * src_n_seg) + (2.0 * 4 + 3.0 * 4) * kBins * ncols);
+        hipLaunchKernelGGL(cdf_hist_lut_kernel, dim3(ncols, a.chunks_t + a.chunks_s), dim3(256), 0, st, a);
     }
-    if ((rc = check_launch("cdf_lut_kernel"))) return rc;
+    if ((rc = check_launch("cdf_hist_lut_kernel"))) return rc;
     const int vec = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0 && aligned16(out) && ldo % 4 == 0 && oss % 4 == 0;
-    long chunk = pick_chunk(nt, ncols, device_cu_count());
+    long chunk = pick_chunk(nt, ncols, n_cu);
     const int chunks = (int)((nt + chunk - 1) / chunk);
     ProfScope prof(KC_APPLY, st, 0.0, 8.0 * (double)nt * ncols);
     hipLaunchKernelGGL(cdf_apply_kernel, dim3(ncols, chunks < 1 ? 1 : chunks), dim3(256), 0, st, target, ldt, tss, nt, C,
                        chunk, w.lo, w.hi, w.lut, out, ldo, oss, vec);
     return check_launch("cdf_apply_kernel");
+}
+
+int minmax_fold_parts(const float* pmn, const float* pmx, int parts, int C, int ncols, float* mn, float* mx, hipStream_t st) {
+    ProfScope prof(KC_MINMAX, st, 0.0, 8.0 * (double)parts * ncols);
+    hipLaunchKernelGGL(minmax_from_parts_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, pmn, pmx, parts, C, ncols, nullptr,
+                       nullptr, 1, mn, mx);
+    return check_launch("minmax_from_parts_kernel");
 }
 
 }  // namespace optex

@@ -480,10 +480,7 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float
     float* cz = cy + (size_t)NS_MAX_ITERS * batch;
     float* fro = cz + (size_t)NS_MAX_ITERS * batch;
     int* k_need = reinterpret_cast<int*>(fro + batch);
-    if (hipMemsetAsync(k_need, 0, sizeof(int), st) != hipSuccess) {
-        set_error("ns_sqrt: cannot clear the iteration count");
-        return OPTEX_E_LAUNCH;
-    }
+    if (int rc0 = device_fill_u32(reinterpret_cast<uint32_t*>(k_need), 0u, 1, st)) return rc0;
     {
         ProfScope prof(KC_NS_INIT, st, 0.0, 12.0 * (double)cc * batch);
         hipLaunchKernelGGL(ns_init_kernel, dim3(batch, NS_INIT_PARTS), dim3(256), 0, st, A, a_ss, C, batch, K, ns_adaptive ? 1 : 0,
@@ -506,14 +503,7 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float
 }
 
 // ------------------------------------------------------------------------------------------------ one transfer operator
-static int dcopy(float* dst, const float* src, size_t count, hipStream_t st) {
-    hipError_t e = hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) {
-        set_error("linalg: device copy failed: %s", hipGetErrorString(e));
-        return OPTEX_E_LAUNCH;
-    }
-    return OPTEX_OK;
-}
+static int dcopy(float* dst, const float* src, size_t count, hipStream_t st) { return device_copy(dst, src, count, st); }
 
 struct TransferWs {
     float *Us, *Ls, *Ut, *Lt;      // chol

@@ -74,11 +74,27 @@ int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float
                    hipStream_t st);
 int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                          int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
-                         const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st);
+                         const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st,
+                         const float* smn_given = nullptr, const float* smx_given = nullptr, bool ws_clean = false);
+// clears the counters of a cdf scratch (its pipeline leaves them clear: once per loop); per-column min / max of segments
+int cdf_ws_clear(void* ws, int C, int n_seg, hipStream_t st);
+int col_minmax_launch(const float* x, long ld, long ss, long n, int C, int n_seg, float* mn, float* mx, hipStream_t st);
+// tmn_parts / tmx_parts (optional): per-tile min / max partials of the TARGET columns [n_seg][parts][C], as the rotation GEMM's
+// row-statistics epilogue leaves them — the rank kernel then starts from the folded range instead of reducing the column
 int sort_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
-                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, hipStream_t st);
+                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, hipStream_t st,
+                    const float* tmn_parts = nullptr, const float* tmx_parts = nullptr, int parts = 0,
+                    const float* src_sorted_given = nullptr);
+// src_sorted_given: the source columns sorted already, [src_n_seg, C, ns] contiguous (`source` is then not read)
+int sort_columns_inplace(float* keys, long n, int ncols, int* flags, hipStream_t st);
+// fold per-tile min / max partials [n_seg][parts][C] into one range per column, mn / mx [n_seg * C] (cdf.hip)
+int minmax_fold_parts(const float* pmn, const float* pmx, int parts, int C, int ncols, float* mn, float* mx, hipStream_t st);
 int linear_stats_parts(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool, float eps, float* mu,
                        float* cov, void* ws, size_t ws_bytes, const float* sum_parts, int parts, void* stream);
 int device_cu_count();
+// device-to-device copy / 32-bit fill as plain kernels on `st` (api.hip): the library enqueues nothing but kernel launches,
+// so a captured hipGraph of any call holds kernel nodes only (tests/test_gpu_parity.py::test_ot_loop_is_hipgraph_capturable).
+int device_copy(float* dst, const float* src, size_t count, hipStream_t st);
+int device_fill_u32(uint32_t* dst, uint32_t value, size_t count, hipStream_t st);
 
 }  // namespace optex

@@ -32,6 +32,7 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float
 namespace {
 
 enum { MODE_CDF = 0, MODE_SORT = 1, MODE_CHOL = 2, MODE_PCA = 3, MODE_SYM = 4 };
+constexpr size_t kHoistBytes = (size_t)1 << 30;  // rotated style copies of all iterations of a call: at most 1 GiB
 constexpr float kEps = 1.0f;  // histmatch.py:5 `eps: float = 1`; no caller overrides it (optex.py:173,200-201)
 
 // bump allocator over the caller's scratch; with base == nullptr it only measures
@@ -71,16 +72,31 @@ struct LoopWs {
     // per-tile row statistics of the rotated pastiche, written by the forward rotation GEMM's epilogue (GemmArgs::rowstat)
     float *rs_a = nullptr, *rs_b = nullptr;
     int rs_parts = 0;
+    // cdf / sort with one rotation sequence for the whole batch: the style side of EVERY iteration is prepared before the
+    // loop (one batched GEMM, one min / max or one sort launch for all of them) — `ys` then holds iters rotated copies
+    bool hoist = false;
+    float *smn_all = nullptr, *smx_all = nullptr;   // cdf: style min / max per (iteration, style segment, channel)
+    int* sort_flags = nullptr;                      // sort: scratch of the one style sort
 
-    // Ss: segments of the ROTATED style the matcher sees (= n_seg when every segment has its own rotations)
-    void layout(Bump& b, int mode, long n, long ns, int C, int n_seg, int Ss, int iters, int fused) {
+    // Ss: segments of the ROTATED style the matcher sees (= n_seg when every segment has its own rotations: own_rot)
+    void layout(Bump& b, int mode, long n, long ns, int C, int n_seg, int Ss, int iters, int fused, bool own_rot) {
         const size_t xs = (size_t)n_seg * C * n, cc = (size_t)C * C;
         rs_parts = gemm_rowstat_parts(n);
         const size_t rs_floats = (size_t)n_seg * rs_parts * C;
         if (mode == MODE_CDF || mode == MODE_SORT) {
             y = b.take<float>(xs);
-            ys = b.take<float>((size_t)Ss * C * ns);
-            if (mode == MODE_CDF && !fused && rs_parts) {
+            const size_t ys_one = (size_t)Ss * C * ns;
+            // (budget: the hoisted copies stay a fraction of the feature maps' own footprint; 2048^2 relu1_1 is not
+            // launch-bound and keeps rotating its style per iteration.  sort: the one-launch sort is the LDS-resident one)
+            hoist = !fused && !own_rot && Ss == 1 && iters > 1 && ys_one * iters * sizeof(float) <= kHoistBytes &&
+                    (mode == MODE_CDF || ns <= 16384);
+            ys = b.take<float>(hoist ? ys_one * iters : ys_one);
+            if (hoist && mode == MODE_CDF) {
+                smn_all = b.take<float>((size_t)iters * Ss * C);
+                smx_all = b.take<float>((size_t)iters * Ss * C);
+            }
+            if (hoist && mode == MODE_SORT) sort_flags = b.take<int>((size_t)iters * Ss * C);
+            if (!fused && rs_parts) {  // cdf: the joint range of histmatch.py:52-53; sort: the rank kernel's bucket range
                 rs_a = b.take<float>(rs_floats);
                 rs_b = b.take<float>(rs_floats);
             }
@@ -143,14 +159,7 @@ struct LoopWs {
     }
 };
 
-int copy_async(float* dst, const float* src, size_t count, hipStream_t st) {
-    hipError_t e = hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) {
-        set_error("optex_ot_loop: device copy failed: %s", hipGetErrorString(e));
-        return OPTEX_E_LAUNCH;
-    }
-    return OPTEX_OK;
-}
+int copy_async(float* dst, const float* src, size_t count, hipStream_t st) { return device_copy(dst, src, count, st); }
 
 // feature-map GEMM with every option spelled out (the C ABI entry point with the loop's fixed layouts)
 int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, int n_seg, const float* bsub, const float* badd,
@@ -360,7 +369,7 @@ extern "C" size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n
     LoopWs w;
     Bump b(nullptr);
     w.layout(b, mode, n, ns, C, n_seg, r_seg_stride != 0 ? n_seg : src_n_seg, iters,
-             (mode < MODE_CHOL && fuse_rotations == 2) ? 0 : fuse_rotations);
+             (mode < MODE_CHOL && fuse_rotations == 2) ? 0 : fuse_rotations, r_seg_stride != 0);
     return b.off;
 }
 
@@ -414,7 +423,7 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
     // With its own rotations every segment sees its own rotated copy of the style: the matchers then run one source
     // segment per target segment (nothing on the style side is shared any more, optex.py:168-171 run per image).
     const int rs_seg = r_seg_stride != 0 ? n_seg : src_n_seg;
-    w.layout(bump, mode, n, ns, C, n_seg, rs_seg, iters, fuse_rotations);
+    w.layout(bump, mode, n, ns, C, n_seg, rs_seg, iters, fuse_rotations, r_seg_stride != 0);
     if (linear)
         return linear_loop(mode, x, n, n_seg, style, ns, src_n_seg, rs_seg, C, R32, Rt32, r_seg_stride, iters, content, strength,
                            fuse_rotations, w, stream);
@@ -460,25 +469,44 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         }
         return OPTEX_OK;
     }
+    int rc;
+    if (w.hoist) {
+        // optex.py:171 for every iteration at once: rotated_style[it] = style_feature @ rotation[it] — one batched GEMM (the
+        // "segments" of the launch are the iterations: one matrix each, all reading the same style map) — and what the
+        // matcher needs of each: its per-channel min / max (cdf, histmatch.py:52-53) or its sorted columns (sort), one
+        // launch for all iterations.  Same arithmetic as inside the loop, 2-4 launches per CALL instead of per iteration.
+        if ((rc = optex_gemm_tn(R32, C, (long)C * C, style, ns, 0, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C,
+                                C, ns, iters, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+            return rc;
+        if (mode == MODE_CDF)
+            rc = col_minmax_launch(w.ys, ns, ss, ns, C, iters * rs_seg, w.smn_all, w.smx_all, st);
+        else
+            rc = sort_columns_inplace(w.ys, ns, iters * rs_seg * C, w.sort_flags, st);
+        if (rc) return rc;
+    }
+    if (mode == MODE_CDF && (rc = cdf_ws_clear(w.mode_ws, C, n_seg, st))) return rc;  // the pipeline leaves its counters clear
     for (int it = 0; it < iters; it++) {
         const float* R = R32 + (size_t)it * C * C;
         const float* Rt = Rt32 + (size_t)it * C * C;
-        int rc;
-        // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (cdf: + per-channel min / max in the epilogue, which
-        // saves histmatch.py:52-53 its own pass over the rotated map)
+        // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (+ per-channel min / max in the epilogue: it saves the
+        // cdf matcher histmatch.py:52-53's pass over the rotated map, and the sort matcher its in-kernel range reduction)
         bool mm = false;
-        if ((rc = rotate_with_stats(R, r_seg_stride, x, w.y, C, n, n_seg, mode == MODE_CDF ? 1 : 0, w.rs_a, w.rs_b, &mm, st)))
-            return rc;
-        // optex.py:171  rotated_style = style_feature @ rotation   (one copy per rotation set)
-        if ((rc = optex_gemm_tn(R, C, r_seg_stride, style, ns, src_n_seg > 1 ? ss : 0, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss,
+        if ((rc = rotate_with_stats(R, r_seg_stride, x, w.y, C, n, n_seg, 1, w.rs_a, w.rs_b, &mm, st))) return rc;
+        // optex.py:171  rotated_style = style_feature @ rotation   (one copy per rotation set; hoisted: done above)
+        const float* ys = w.hoist ? w.ys + (size_t)it * rs_seg * ss : w.ys;
+        if (!w.hoist &&
+            (rc = optex_gemm_tn(R, C, r_seg_stride, style, ns, src_n_seg > 1 ? ss : 0, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss,
                                 OPTEX_CHANNEL_MAJOR, C, C, ns, rs_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
             return rc;
         // optex.py:173  hist_match(rotated_pastiche, rotated_style), in place
         if (mode == MODE_CDF)
-            rc = cdf_match_parts_impl(w.y, n, xs, n, w.ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr,
-                                      mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, st);
+            rc = cdf_match_parts_impl(w.y, n, xs, n, ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr,
+                                      mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, st,
+                                      w.hoist ? w.smn_all + (size_t)it * rs_seg * C : nullptr,
+                                      w.hoist ? w.smx_all + (size_t)it * rs_seg * C : nullptr, true);
         else
-            rc = sort_match_impl(w.y, n, xs, n, w.ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, st);
+            rc = sort_match_impl(w.y, n, xs, n, ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, st,
+                                 mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, w.hoist ? ys : nullptr);
         if (rc) return rc;
         // optex.py:175 + 115-117  pastiche = matched @ rotation.T ; content blend
         if ((rc = optex_gemm_tn(Rt, C, r_seg_stride, w.y, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,

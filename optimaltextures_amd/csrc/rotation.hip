@@ -3,8 +3,9 @@
 // scipy runs N-1 Householder reflections in a Python loop on the host (140 ms at N = 256).  The reflections act on
 // the ROWS of H independently ( H[i, n:] -= (H[i, n:] . x_n) x_n ), so the O(N^3) part is embarrassingly parallel over
 // rows: one wavefront per row keeps its row in registers and replays the N-1 reflections in order, in fp64 like scipy.
-// The random stream itself (numpy's legacy MT19937 gaussian stream, so that np.random.seed reproduces the reference's
-// matrices) stays on the host; the normals are uploaded once per batch of rotations.
+// The random stream itself is numpy's legacy MT19937 gaussian stream (so that np.random.seed reproduces the reference's
+// matrices).  It can stay on the host (the normals are then uploaded once per batch of rotations) or run on the device:
+// legacy_normals_kernel below advances a stream from its 624-word state exactly as numpy's RandomState.normal does.
 // Differences to scipy are fp64 summation-order effects (~1e-16), invisible after optex.py:168's cast to fp32 except
 // for rare 1-ulp flips.
 #include "optex_common.h"
@@ -78,9 +79,161 @@ __global__ __launch_bounds__(64) void householder_apply_kernel(const double* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------ numpy's legacy gaussian stream
+// RandomState.normal(size) = MT19937 (Matsumoto & Nishimura) + numpy's legacy polar method with its one-value cache
+// (numpy/random/src/legacy/legacy-distributions.c legacy_gauss; restated on the host in oracle/optex_oracle.c:60-131):
+//     do { x1 = 2 u() - 1; x2 = 2 u() - 1; r2 = x1 x1 + x2 x2; } while (r2 >= 1 || r2 == 0);
+//     f = sqrt(-2 log(r2) / r2);  return f x2, then (cached) f x1;       u() = ((w >> 5) 2^26 + (w' >> 6)) / 2^53
+// Sequential as written, parallel in fact: an ATTEMPT always consumes exactly four 32-bit words whether it is accepted or
+// not, so attempt j of a stretch of the stream is a pure function of words 4j .. 4j + 3, and the outputs are the accepted
+// attempts in order (a prefix sum of the accept flags).  The MT19937 recurrence x[k + 624] = x[k + 397] ^ t(x[k], x[k + 1])
+// is itself parallel 227 wide.  One workgroup of 256 threads per stream: per round it regenerates the 624-word block in
+// three 227-wide phases (out of place: no read-before-write hazards), tempers it, evaluates the <= 157 attempts of the
+// block in parallel and writes the accepted pairs behind each other.  State in / out: 624 key words, the position inside the
+// block, the cache flag and the cached value — numpy's RandomState.get_state() tuple, so a stream can be handed over
+// from / to the host at any point.  Every operation is IEEE (no contraction, correctly rounded division and square root)
+// and identical to the host's, except log(): the device's log is within 1 ulp of the host libm's, so a draw equals
+// numpy's bit for bit in most cases and differs by one unit in the last place of a double otherwise
+// (tests/test_gpu_parity.py::test_device_normals_follow_numpy_stream).
+constexpr int MT_N = 624, MT_M = 397, MT_STATE_WORDS = MT_N + 4;   // key, pos, has_gauss, gauss (2 words)
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t far) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+__device__ __forceinline__ double mt_unit(uint32_t w0, uint32_t w1) {
+    return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
+}
+
+__global__ __launch_bounds__(256) void legacy_normals_kernel(uint32_t* __restrict__ states, long count, double* __restrict__ out,
+                                                             long out_stride) {
+    __shared__ uint32_t key[2][MT_N];   // the block, ping-pong
+    __shared__ uint32_t sw[MT_N + 4];   // tempered words still to be consumed: <= 3 carried over + the rest of the block
+    __shared__ uint32_t wtot[4];
+    __shared__ int s_stop;
+    __shared__ double s_cache;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* st = states + (size_t)blockIdx.x * MT_STATE_WORDS;
+    double* o = out + (size_t)blockIdx.x * out_stride;
+    for (int i = tid; i < MT_N; i += 256) key[0][i] = st[i];
+    // uniform bookkeeping: block in use, position inside it, words carried over, values delivered, cache state
+    int cur = 0, pos = (int)st[MT_N], carry = 0, has = (int)st[MT_N + 1];
+    long done = 0;
+    if (tid == 0) s_cache = *reinterpret_cast<const double*>(st + MT_N + 2);
+    __syncthreads();
+    if (count > 0 && has) {   // the cached second value of the last accepted pair goes out first
+        if (tid == 0) o[0] = s_cache;
+        done = 1;
+        has = 0;
+    }
+    while (done < count) {
+        if (pos >= MT_N) {
+            // next block, out of place: key[cur] -> key[cur ^ 1], three phases of up to 227 independent words
+            const uint32_t* a = key[cur];
+            uint32_t* b = key[cur ^ 1];
+            constexpr int W = MT_N - MT_M;  // 227
+            if (tid < W) b[tid] = mt_twist(a[tid], a[tid + 1], a[tid + MT_M]);
+            __syncthreads();
+            if (tid < W) b[tid + W] = mt_twist(a[tid + W], a[tid + W + 1], b[tid]);
+            __syncthreads();
+            if (tid < MT_N - 2 * W) {
+                const int k = tid + 2 * W;
+                b[k] = mt_twist(a[k], k + 1 < MT_N ? a[k + 1] : b[0], b[k - W]);
+            }
+            __syncthreads();
+            cur ^= 1;
+            pos = 0;
+        }
+        // the rest of the block, tempered, behind the words carried over from the last one
+        const int avail = MT_N - pos, total = carry + avail, nat = total >> 2;
+        for (int i = tid; i < avail; i += 256) sw[carry + i] = mt_temper(key[cur][pos + i]);
+        __syncthreads();
+        bool acc = false;
+        double v2 = 0.0, v1 = 0.0;
+        if (tid < nat) {
+            const double x1 = 2.0 * mt_unit(sw[4 * tid], sw[4 * tid + 1]) - 1.0;
+            const double x2 = 2.0 * mt_unit(sw[4 * tid + 2], sw[4 * tid + 3]) - 1.0;
+            const double r2 = x1 * x1 + x2 * x2;
+            acc = !(r2 >= 1.0 || r2 == 0.0);
+            if (acc) {
+                const double f = sqrt(-2.0 * log(r2) / r2);
+                v2 = f * x2;
+                v1 = f * x1;
+            }
+        }
+        const unsigned long long bal = __ballot(acc);
+        if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        long before = (long)__popcll(bal & ((1ull << lane) - 1ull));   // accepted attempts in front of mine
+        for (int k = 0; k < wave; k++) before += wtot[k];
+        const long accepted = (long)wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        const long room = count - done;   // values still wanted
+        // accepted attempt number `before` delivers values 2 * before and 2 * before + 1 of this round
+        if (acc && 2 * before < room) {
+            o[done + 2 * before] = v2;
+            if (2 * before + 1 < room) o[done + 2 * before + 1] = v1;
+        }
+        if (2 * accepted >= room) {
+            // The stream stops inside this round, behind the attempt that delivers value number room - 1: the words after
+            // it stay unconsumed, and an odd `room` leaves that attempt's second value in the cache.
+            if (acc && before == (room - 1) / 2) {
+                s_stop = tid;
+                s_cache = v1;
+            }
+            __syncthreads();
+            pos += 4 * (s_stop + 1) - carry;   // words of THIS block consumed from pos on (the carried ones were the last block's)
+            carry = 0;
+            has = (int)(room & 1);
+            done = count;
+        } else {
+            done += 2 * accepted;
+            const int left = total - 4 * nat;  // up to three words are left over: they open the next round
+            uint32_t keep = 0u;
+            if (tid < left) keep = sw[4 * nat + tid];
+            __syncthreads();
+            if (tid < left) sw[tid] = keep;
+            carry = left;
+            pos = MT_N;
+            has = 0;
+        }
+    }
+    __syncthreads();
+    // hand the state back (the loop leaves through its stop branch: nothing is carried over here)
+    for (int i = tid; i < MT_N; i += 256) st[i] = key[cur][i];
+    if (tid == 0) {
+        st[MT_N] = (uint32_t)pos;
+        st[MT_N + 1] = (uint32_t)has;
+        *reinterpret_cast<double*>(st + MT_N + 2) = has ? s_cache : 0.0;
+    }
+}
+
 }  // namespace optex
 
 using namespace optex;
+
+extern "C" size_t optex_mt19937_state_bytes(void) { return (size_t)MT_STATE_WORDS * sizeof(uint32_t); }
+
+extern "C" int optex_legacy_normals(void* states, int n_streams, long count, double* out, long out_stride, void* stream) {
+    if (!states || !out || n_streams <= 0 || count < 0 || out_stride < count) {
+        set_error("optex_legacy_normals: bad argument (n_streams=%d count=%ld out_stride=%ld)", n_streams, count, out_stride);
+        return OPTEX_E_ARG;
+    }
+    if (count == 0) return OPTEX_OK;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(KC_ROTGEN, st, 0.0, 8.0 * (double)count * n_streams);
+    hipLaunchKernelGGL(legacy_normals_kernel, dim3(n_streams), dim3(256), 0, st, static_cast<uint32_t*>(states), count, out,
+                       out_stride);
+    return check_launch("legacy_normals_kernel");
+}
 
 extern "C" long optex_rotation_normals(int N) { return (long)N * (N + 1) / 2 - 1; }
 

@@ -190,11 +190,7 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
     a.inv_2nt = 1.0 / (2.0 * (double)a.n);
     int rc;
     if (use_rank) {
-        hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)ncols, st);
-        if (e != hipSuccess) {
-            set_error("sort: memset failed: %s", hipGetErrorString(e));
-            return OPTEX_E_LAUNCH;
-        }
+        if ((rc = device_fill_u32(reinterpret_cast<uint32_t*>(flags), 0u, (size_t)ncols, st))) return rc;
         {
             ProfScope prof(MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH, st, 0.0, per_elem * (double)a.n * ncols);
             if ((rc = launch_rank4(MODE, a, ncols, st))) return rc;  // owner-ranked, float domain (sort_rank4.hip)
@@ -215,6 +211,7 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
 }
 
 static size_t flags_bytes(int ncols) { return align_up(sizeof(int) * (size_t)ncols, 256); }
+static size_t range_bytes(int ncols) { return 2 * align_up(sizeof(float) * (size_t)ncols, 256); }  // lo, hi per target column
 
 template <int MODE>
 static int launch_sort(const SortArgs& a, int ncols, int* flags, void* large_ws, hipStream_t st) {
@@ -227,23 +224,53 @@ static int launch_sort(const SortArgs& a, int ncols, int* flags, void* large_ws,
     return sort_large(MODE, a, ncols, large_ws, st);
 }
 
-int sort_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
-                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, hipStream_t st) {
-    // ws: [flags for the larger launch][sorted source keys [src_n_seg, C, ns]][scratch of the large-column path]
-    int* flags = static_cast<int*>(ws);
-    float* ssorted = reinterpret_cast<float*>(static_cast<char*>(ws) + flags_bytes(C * n_seg));
-    void* large_ws = reinterpret_cast<char*>(ssorted) + align_up((size_t)src_n_seg * C * ns * sizeof(float), 256);
-    // 1. sort the source columns (keys only)
+// keys [ncols][n] contiguous, sorted IN PLACE (keys only; n <= SORT_MAX_N): the rank kernel holds a whole column in
+// registers before it writes, and so does the radix sweep behind it.  flags: ncols ints of scratch.
+int sort_columns_inplace(float* keys, long n, int ncols, int* flags, hipStream_t st) {
+    if (n > SORT_MAX_N) {
+        set_error("sort_columns_inplace: columns of %ld keys (at most %d)", n, SORT_MAX_N);
+        return OPTEX_E_UNSUPPORTED;
+    }
     SortArgs s{};
-    s.keys = source; s.ld = lds; s.ss = sss; s.n = ns; s.C = C; s.x_n_seg = src_n_seg;
-    s.out_keys = ssorted; s.out_idx = nullptr;
-    int rc = launch_sort<SORT_EMIT>(s, C * src_n_seg, flags, large_ws, st);
-    if (rc) return rc;
+    s.keys = keys; s.ld = n; s.ss = n; s.n = n; s.C = 1; s.x_n_seg = ncols;
+    s.out_keys = keys; s.out_idx = nullptr;
+    return launch_sort<SORT_EMIT>(s, ncols, flags, nullptr, st);
+}
+
+int sort_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
+                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, hipStream_t st,
+                    const float* tmn_parts, const float* tmx_parts, int parts, const float* src_sorted_given) {
+    // ws: [flags for the larger launch][lo, hi per target column][sorted source keys [src_n_seg, C, ns]][scratch of the
+    //      large-column path]
+    const int maxcols = C * (n_seg > src_n_seg ? n_seg : src_n_seg);
+    int* flags = static_cast<int*>(ws);
+    float* rlo = reinterpret_cast<float*>(static_cast<char*>(ws) + flags_bytes(maxcols));
+    float* rhi = reinterpret_cast<float*>(reinterpret_cast<char*>(rlo) + range_bytes(C * n_seg) / 2);
+    float* ssorted = reinterpret_cast<float*>(reinterpret_cast<char*>(rlo) + range_bytes(C * n_seg));
+    void* large_ws = reinterpret_cast<char*>(ssorted) + align_up((size_t)src_n_seg * C * ns * sizeof(float), 256);
+    // 1. sort the source columns (keys only) — unless the caller did (optex_ot_loop sorts the rotated style of every
+    //    iteration of a call in one launch)
+    int rc;
+    if (src_sorted_given) {
+        ssorted = const_cast<float*>(src_sorted_given);  // [src_n_seg, C, ns] contiguous, read only
+    } else {
+        SortArgs s{};
+        s.keys = source; s.ld = lds; s.ss = sss; s.n = ns; s.C = C; s.x_n_seg = src_n_seg;
+        s.out_keys = ssorted; s.out_idx = nullptr;
+        if ((rc = launch_sort<SORT_EMIT>(s, C * src_n_seg, flags, large_ws, st))) return rc;
+    }
     // 2. rank each target column and fetch the source quantiles
     SortArgs t{};
     t.keys = target; t.ld = ldt; t.ss = tss; t.n = nt; t.C = C; t.x_n_seg = n_seg;
     t.src_sorted = ssorted; t.ns = ns; t.src_n_seg = src_n_seg;
     t.out = out; t.ldo = ldo; t.oss = oss;
+    if (tmn_parts && tmx_parts && parts > 0 && nt >= RK_MIN_N && nt <= SORT_MAX_N) {
+        // the range of every target column from the partials the rotation GEMM left (optex_ot_loop): the rank kernel skips
+        // its own min / max reduction and the barrier behind it
+        if ((rc = minmax_fold_parts(tmn_parts, tmx_parts, parts, C, C * n_seg, rlo, rhi, st))) return rc;
+        t.rng_lo = rlo;
+        t.rng_hi = rhi;
+    }
     return launch_sort<SORT_MATCH>(t, C * n_seg, flags, large_ws, st);
 }
 
@@ -274,8 +301,8 @@ extern "C" size_t optex_sort_match_ws_bytes(long nt, long ns, int C, int n_seg, 
     size_t large = 0;
     if (nt > SORT_MAX_N) large = sort_large_ws_bytes(nt, C * n_seg);
     if (ns > SORT_MAX_N && sort_large_ws_bytes(ns, C * src_n_seg) > large) large = sort_large_ws_bytes(ns, C * src_n_seg);
-    return flags_bytes(C * (n_seg > src_n_seg ? n_seg : src_n_seg)) + align_up((size_t)src_n_seg * C * ns * sizeof(float), 256) +
-           large;
+    return flags_bytes(C * (n_seg > src_n_seg ? n_seg : src_n_seg)) + range_bytes(C * n_seg) +
+           align_up((size_t)src_n_seg * C * ns * sizeof(float), 256) + large;
 }
 
 extern "C" int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt, const float* source,

@@ -39,6 +39,9 @@ struct SortArgs {
     double inv_2nt;                                           // 1 / (2 * n) for the quantile index
     int ncols;                                                // C * n_seg
     int out_vec;                                              // rank_match4_kernel: `out` takes 16-byte stores
+    // optional, rank_match4_kernel: the column's min / max [ncols] when the caller has them already (optex_ot_loop: the
+    // rotation GEMM's row-statistics epilogue) — the kernel then skips its own reduction and the barrier behind it
+    const float* rng_lo; const float* rng_hi;
 #ifdef OPTEX_SORT_PROBE
     long long* probe;                                         // [ncols, 16] phase timestamps (scripts/sort_phase_probe.hip)
 #endif

@@ -227,6 +227,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // ---- 1. min / max; non-finite keys (x * 0 is NaN); non-zero keys below 2^-100 (the counting of step 7 is exact only
     //         if distinct keys differ by 2^-127 or more)
     float lo = x[0], hi = x[0], nf = 0.f, tz = 0.f;
+    const bool range_given = a.rng_lo != nullptr;  // uniform: the caller knows the column's range (SortArgs::rng_lo)
+    if (range_given) {
+        // The range comes from the rotation GEMM's epilogue (min / max of exactly the values stored here): no reduction, and
+        // the barrier below only publishes the zeroed counters — it is passed while the column is still on its way from
+        // HBM, every wavefront then goes on as soon as ITS keys are there.  v_min / v_max drop NaN, so the non-finite /
+        // tiny-key test stays per key; it reports through misc[22] (read behind the scan's barrier, before anything is stored).
+        lo = a.rng_lo[col];
+        hi = a.rng_hi[col];
+        __syncthreads();
+        const float p100 = 1.2676506e30f;  // 2^100
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            float p, z;
+            asm("v_fma_f32 %0, %3, 0, %0\n\t"
+                "v_mul_f32_e64 %1, |%3|, %4 clamp\n\t"
+                "v_fma_f32 %2, -%1, %1, %1\n\t"
+                : "+v"(nf), "=&v"(p), "=&v"(z)
+                : "v"(x[r]), "s"(p100));
+            tz += z;
+        }
+        const bool bad = !(nf == 0.f) || tz > 0.f;
+        if (__any(bad) && lane == 0) misc[22] = 1u;
+    } else {
     {
         const float p100 = 1.2676506e30f;  // 2^100
 #pragma unroll
@@ -276,6 +299,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (int k = 0; k < NW; k++) {
         lo = r4_min(lo, __uint_as_float(red[k]));
         hi = r4_max(hi, __uint_as_float(red[16 + k]));
+    }
     }
     // (red is next written by the scan of step 5, two barriers from here)
     if (!(hi < __uint_as_float(R4_INF)) || !(lo > -__uint_as_float(R4_INF))) {  // non-finite / tiny keys: radix kernel
@@ -477,7 +501,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     __syncthreads();
     const unsigned nbig = misc[0];
-    if (nbig > RK_MAXBIG) {
+    if (nbig > RK_MAXBIG || misc[22] != 0u) {  // (misc[22]: a non-finite or tiny key under a caller-given range, step 1)
         if (tid == 0) a.flags[col] = 1;
         return;
     }
@@ -664,6 +688,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (tid == 0) a.flags[col] = 1;
         return;
     }
+    if (qn != 0u) {  // uniform: a column without a crossing bucket or an equal pair of keys skips the phase and its barriers
     for (uint32_t i = tid; i < qn; i += NT) {
         const float k = __uint_as_float(qkey[i]);
         const uint32_t w0p = qwin[i];
@@ -682,7 +707,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             r4_count4(lt, le, xl, k);
         }
         qres[i] = w0p + lt;
-        if (le - lt > 1u) {  // a handful per column (equal fp32 keys, -0 / +0): compacted, so that nobody scans the whole queue
+        if (le - lt > 1u) {  // equal fp32 keys, -0 / +0: compacted, so that nobody scans the whole queue
             const uint32_t t = atomicAdd(&misc[21], 1u);
             if (t < (uint32_t)TCAP) tlist[t] = i;
         }
@@ -708,6 +733,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         qres[i] += before;  // only this thread touches qres[i]
     }
     __syncthreads();
+    }
     SORT_PROBE(8);
     if (MODE == SORT_EMIT) {
         // ---- 9E. sorted keys / pixel indices: every owner writes its key (then its pixel number) to slot[rank] — every
@@ -762,11 +788,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             for (unsigned e = tid; e < ns; e += NT) val[e] = ssrt[e];
         }
     }
+    if (qn != 0u) {
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        if ((ba[r] & R4_TAG) != 0u) ba[r] = qres[ba[r] & ~R4_TAG];  // rare: most wavefront rows branch over it
+        for (int r = 0; r < ITEMS; r++) {
+            if ((ba[r] & R4_TAG) != 0u) ba[r] = qres[ba[r] & ~R4_TAG];  // rare: most wavefront rows branch over it
+        }
     }
-    __syncthreads();
+    if (stage) __syncthreads();  // the staged column is complete (without staging nothing was written since the last barrier)
     SORT_PROBE(9);
     // the uniform decisions — staged column (LDS) or global gather, identity quantile when ns == n — are branches around
     // whole loops: selected per key they turn the LDS read into a flat load with a 64-bit address select

@@ -256,6 +256,14 @@ def rotation_rng(seed: int, group: int):
     return np.random.RandomState(rotation_seed(seed, group))
 
 
+def rotation_stream(seed: int, groups, device):
+    """the same numpy stream(s) as rotation_rng, advanced on the GPU (rotation.DeviceNormals): `groups` is one rotation group
+    (one sequence shared by its textures) or a list of them (one sequence per texture, group size 1)"""
+    from .rotation import DeviceNormals
+    many = isinstance(groups, (list, tuple, range))
+    return DeviceNormals([rotation_rng(seed, g) for g in (groups if many else [groups])], device)
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

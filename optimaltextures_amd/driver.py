@@ -211,6 +211,20 @@ def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content:
     s, c, n = x.shape
     if iters <= 0:
         return x
+    if isinstance(rng, rotation.DeviceNormals):
+        # the numpy stream(s) advanced on the GPU: one stream = one sequence shared by the batch, S streams = one per texture
+        if rng.n != 1 and (pooled or rng.n != s):
+            raise ValueError(f"per-texture rotation streams need independent textures and one stream per texture (got {rng.n} for {s})")
+        if hist_mode not in LOOP_MODES:
+            raise ValueError(f"hist_mode must be one of chol|pca|sym|cdf|sort, got {hist_mode!r}")
+        if rng.n != 1 and hist_mode in LINEAR_MODES and c > ops.LINEAR_MAX_C:
+            raise NotImplementedError(f"per-texture rotation sequences need C <= {ops.LINEAR_MAX_C} in the linear modes")
+        R32, Rt32 = rng.rotations(c, iters)
+        if content is not None and content.shape[0] != s:
+            content = content.expand(s, c, n).contiguous()
+        if rng.n != 1:
+            return ops.ot_loop(hist_mode, x, style, R32, Rt32, content=content, strength=strength)
+        return _shared_rotation_iterations(x, style, hist_mode, R32, Rt32, content, strength, pooled, fuse_rotations)
     if isinstance(rng, (list, tuple)):
         # one numpy stream per texture: every segment draws its own rotations, like the reference run once per image
         if pooled or len(rng) != s:
@@ -224,6 +238,13 @@ def ot_iterations(x: Tensor, style: Tensor, hist_mode: str, iters: int, content:
     R32, Rt32 = rotation.rotations(c, iters, x.device, rng=rng)
     if content is not None and content.shape[0] != s:
         content = content.expand(s, c, n).contiguous()
+    return _shared_rotation_iterations(x, style, hist_mode, R32, Rt32, content, strength, pooled, fuse_rotations)
+
+
+def _shared_rotation_iterations(x, style, hist_mode, R32, Rt32, content, strength, pooled, fuse_rotations):
+    """the iterations of one (pass, layer) with ONE rotation sequence for the whole batch (optex.py:168-170)"""
+    s, c, n = x.shape
+    iters = R32.shape[0]
     if pooled and s > 1:
         return _pooled_iterations(x, style, hist_mode, R32, Rt32, content, strength)
     if hist_mode not in LOOP_MODES:
@@ -459,6 +480,18 @@ class OptimalTexture(torch.nn.Module):
         # with PCA: all fits of the call up front too (one batched eigensolve per layer width instead of one call per fit)
         sides = (self.prefetch_style_sides(pastiche.shape[-2:], styles, content)
                  if (self.style_sync is not None or self.use_pca) else None)
+        if isinstance(self.rng, rotation.DeviceNormals):
+            # device-side numpy stream(s): the draws of the whole call go out now, on the generator's side stream — they
+            # depend on nothing but the stream state and the (known) sizes, so they run beside the convolutions
+            schedule = []
+            for p in range(self.passes):
+                for li, encoder in enumerate(self.encoders):
+                    enc_index = li if self.index_by_position else 5 - encoder.depth
+                    c = int(sides[p][2][li].shape[1]) if self.use_pca else encoder.out_shape(16, 16)[0]
+                    schedule.append((c, layer_iters(self.iters_per_pass_and_layer, p, enc_index)))
+            if self.color_transfer == "opt":
+                schedule.append((3, 3))
+            self.rng.prefetch(schedule)
         for p in range(self.passes):
             if verbose:
                 print(f"Pass {p}, size {self.sizes[p]}")

@@ -1,12 +1,16 @@
-"""Host side of the SO(N) generator (optex.py:142-149): the numpy-legacy gaussian stream that scipy's
+"""The random side of the SO(N) generator (optex.py:142-149): the numpy-legacy gaussian stream that scipy's
 special_ortho_group.rvs consumes.  Drawing from numpy's GLOBAL RandomState (the default) reproduces the reference's
-matrices after np.random.seed(s); the O(N^3) Householder accumulation runs on the GPU (csrc/rotation.hip)."""
+matrices after np.random.seed(s); the O(N^3) Householder accumulation runs on the GPU (csrc/rotation.hip).  The stream
+itself can run on the GPU too (DeviceNormals): same MT19937 words, same polar method and cache, advanced by
+optex_legacy_normals from numpy's own state tuple."""
 import os
+from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
+import torch
 
-from . import ops
+from . import _lib, ops
 
 _pool = None
 
@@ -46,3 +50,91 @@ def rotations_per_segment(N: int, count: int, device, rngs):
     list(_pool.map(draw, range(S)))
     R32, Rt32 = ops.rotations_from_normals(normals.reshape(S * count, per), int(N), S * count, device)
     return R32.view(S, count, N, N), Rt32.view(S, count, N, N)
+
+
+class DeviceNormals:
+    """numpy RandomState gaussian streams that live on the GPU (csrc/rotation.hip legacy_normals_kernel, ABI 7).
+
+    Built from numpy RandomState objects (or seeds): their get_state() tuples are copied to the device once, from then on
+    every draw is a kernel — one workgroup per stream — and the host never touches a normal again: no 17 ms of
+    RandomState.normal and no 24 ms of pageable host-to-device copies per 52-iteration step (scripts/host_profile.py), and
+    64 per-texture streams advance side by side instead of on a host thread pool.  The values are numpy's (bit for bit
+    except where the device's log() differs from the host libm's by one unit in the last place).
+
+    One stream: rotations(N, count) -> (R32 [count, N, N], Rt32), the whole batch shares the sequence like the reference's
+    --batch (optex.py:168-170).  S streams: -> ([S, count, N, N], ...), one sequence per texture (the reference run once
+    per image).  The kernels run on a side stream; prefetch(schedule) enqueues the draws of a whole forward call up front
+    (they are sequentially dependent through the state, but independent of the features), so they overlap the
+    convolutions and the OT loops find their rotations ready."""
+
+    def __init__(self, rngs, device, side_stream: bool = True):
+        rngs = list(rngs) if isinstance(rngs, (list, tuple)) else [rngs]
+        words = _lib.load().optex_mt19937_state_bytes() // 4
+        host = np.zeros((len(rngs), words), dtype=np.uint32)
+        for i, r in enumerate(rngs):
+            if not isinstance(r, np.random.RandomState):
+                r = np.random.RandomState(int(r))
+            name, key, pos, has_gauss, cached = r.get_state()
+            assert name == "MT19937" and key.shape == (624,)
+            host[i, :624] = key
+            host[i, 624] = pos
+            host[i, 625] = has_gauss
+            host[i, 626:628] = np.frombuffer(np.float64(cached).tobytes(), dtype=np.uint32)
+        self.device = torch.device(device)
+        self.n = len(rngs)
+        self.states = torch.from_numpy(host.view(np.int32)).to(self.device)
+        self.stream = torch.cuda.Stream(self.device) if side_stream else None
+        self._queue = deque()   # prefetched draws in stream order: (N, count, normals, event)
+
+    def state(self, i: int = 0):
+        """the stream's state as numpy's get_state() tuple (a host synchronisation: tests, hand-over back to the host)"""
+        w = self.states[i].cpu().numpy().view(np.uint32)
+        return ("MT19937", w[:624].copy(), int(w[624]), int(w[625]), float(np.frombuffer(w[626:628].tobytes(), dtype=np.float64)[0]))
+
+    def draw(self, total: int):
+        """the next `total` values of every stream: ([n, total] float64 on the device, event recorded behind the draw or None)"""
+        lib = _lib.lib()
+        cur = torch.cuda.current_stream(self.device)
+        run = self.stream if self.stream is not None else cur
+        with torch.cuda.stream(run):
+            out = torch.empty((self.n, int(total)), dtype=torch.float64, device=self.device)
+            _lib.check(lib.optex_legacy_normals(_lib.ptr(self.states), self.n, int(total), _lib.ptr(out), int(total),
+                                                ctypes_stream(run)))
+            ev = None
+            if self.stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(run)
+        return out, ev
+
+    def prefetch(self, schedule):
+        """schedule: [(N, count), ...] in the order the rotations will be asked for"""
+        for N, count in schedule:
+            if count > 0:
+                per = ops.rotation_normals(int(N))
+                normals, ev = self.draw(int(count) * per)
+                self._queue.append((int(N), int(count), normals, ev))
+
+    def rotations(self, N: int, count: int):
+        if N is None or not np.isscalar(N) or N <= 1 or N != int(N):
+            raise ValueError("Dimension of rotation must be specified,\n and must be a scalar greater than 1.")
+        N, count = int(N), int(count)
+        if self._queue:
+            qn, qc, normals, ev = self._queue.popleft()
+            if (qn, qc) != (N, count):
+                raise RuntimeError(f"DeviceNormals: prefetched rotations ({qc} of size {qn}) do not match the request "
+                                   f"({count} of size {N}): the stream has advanced past it")
+        else:
+            normals, ev = self.draw(count * ops.rotation_normals(N))
+        cur = torch.cuda.current_stream(self.device)
+        if ev is not None:
+            cur.wait_event(ev)
+            normals.record_stream(cur)
+        R32, Rt32 = ops.rotations_from_normals(normals.view(self.n * count, -1), N, self.n * count, self.device)
+        if self.n == 1:
+            return R32, Rt32
+        return R32.view(self.n, count, N, N), Rt32.view(self.n, count, N, N)
+
+
+def ctypes_stream(stream):
+    import ctypes
+    return ctypes.c_void_p(stream.cuda_stream)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Where does a SMALL batch lose throughput?  bench.py's step at B textures per step (BASELINE config 4 shards 8 per GPU),
+three ways: as the bench runs it (rotations drawn from the numpy stream inside the step), with the rotations of every
+(pass, layer) cached on the device beforehand (no host RNG, no host->device copy inside the step: the GPU-side bound), and
+the host cost of drawing one step's normals alone.
+    python scripts/batch_probe.py [B ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from optimaltextures_amd import dist as otdist, rotation  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = True
+    style = bench.synthetic_style(dev)
+    tex = bench.make_texturizer("cdf", dev)
+    sizes = [int(a) for a in sys.argv[1:]] or [8, 16, 64]
+    for B in sizes:
+        steps = max(3, 96 // B)
+
+        def run(n):
+            for q in range(n):
+                tex.rng = otdist.rotation_rng(0, q)
+                tex.forward(otdist.texture_noise(q * B, B, (3, 512, 512), dev), [style])
+
+        with torch.inference_mode():
+            run(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(steps)
+            host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            live = time.perf_counter() - t0
+            # the same steps with every rotation batch of the call served from a device-side cache
+            cache, own = {}, rotation.rotations
+
+            def cached(N, count, device, rng=None, want64=False):
+                key = (N, count)
+                if key not in cache:
+                    cache[key] = own(N, count, device, rng=np.random.RandomState(1))
+                return cache[key]
+
+            rotation.rotations = cached
+            import optimaltextures_amd.driver as drv
+            drv.rotation.rotations = cached
+            run(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(steps)
+            host_c = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            gpu = time.perf_counter() - t0
+            rotation.rotations = own
+            drv.rotation.rotations = own
+        t0 = time.perf_counter()
+        r = np.random.RandomState(0)
+        for it in (13, 12, 10, 9, 8):
+            r.normal(size=(it, 256 * 257 // 2 - 1))
+        draw = time.perf_counter() - t0
+        print(f"B = {B:3d}: live {B * steps / live:7.1f} textures/s ({1e3 * live / steps:6.1f} ms/step, host enqueue {1e3 * host / steps:6.1f} ms) | "
+              f"cached rotations {B * steps / gpu:7.1f} textures/s ({1e3 * gpu / steps:6.1f} ms/step, host enqueue {1e3 * host_c / steps:6.1f} ms) | "
+              f"drawing one step's 1.71 M normals on the host: {1e3 * draw:.1f} ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/optex.h but not exported by liboptex_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes and header disagree"
-    assert lib.optex_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.optex_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_size_helpers_need_no_gpu():
@@ -48,6 +48,20 @@ def test_argument_errors_are_reported_without_launching():
     assert b"optex_vgg_glue_layout" in lib.optex_last_error()
     assert lib.optex_vgg_glue_layout(ptr, None, ptr, 1, 3, 4, 4, 0, 0, 0, 0, 1, 1, None) != 0
     assert b"C % 4" in lib.optex_last_error()
+
+
+def test_round4_entry_points_check_their_arguments_without_launching():
+    """optex_legacy_normals (ABI 7): the device side of numpy's gaussian stream refuses bad calls on the host; the state is
+    numpy's get_state() tuple, 624 + 4 words"""
+    import ctypes
+    lib = _lib.load()
+    assert lib.optex_mt19937_state_bytes() == (624 + 4) * 4
+    buf = (ctypes.c_uint32 * 628)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.optex_legacy_normals(None, 1, 10, p, 10, None) == -1 and b"optex_legacy_normals" in lib.optex_last_error()
+    assert lib.optex_legacy_normals(p, 1, 10, p, 5, None) == -1      # out_stride smaller than count
+    assert lib.optex_legacy_normals(p, 0, 10, p, 10, None) == -1
+    assert lib.optex_legacy_normals(p, 1, 0, p, 0, None) == 0        # nothing to draw: no launch
 
 
 def test_round3_entry_points_check_their_arguments_without_launching():

@@ -857,6 +857,103 @@ def test_ot_loop_is_hipgraph_capturable(dev, mode, C, blend):
         static_x.copy_(x0)
 
 
+# ================================================================================================ the numpy stream on the device
+def _ulps(a, b):
+    return np.abs(a.view(np.int64) - b.view(np.int64))
+
+
+@pytest.mark.parametrize("count", [1, 2, 7, 311, 312, 313, 1000, 32895, 200001])
+def test_device_normals_follow_numpy_stream(dev, count):
+    """optex_legacy_normals (ABI 7): numpy's RandomState.normal — MT19937 + legacy polar method with its cache, what scipy's
+    special_ortho_group.rvs draws from (optex.py:149) — advanced on the GPU from numpy's own state tuple.  Same words, same
+    accept / reject decisions, same cache; every value equals numpy's bit for bit or, where the device's log() rounds the
+    other way, differs by ONE unit in the last place of the double.  The state handed back is numpy's state after the same
+    draws, so host and device can take turns on one stream."""
+    from optimaltextures_amd.rotation import DeviceNormals
+    seeds = [123, 7, 2 ** 31 + 5]
+    dn = DeviceNormals([np.random.RandomState(sd) for sd in seeds], dev, side_stream=False)
+    got = dn.draw(count)[0].cpu().numpy()
+    refs = [np.random.RandomState(sd) for sd in seeds]
+    want = np.stack([r.normal(size=count) for r in refs])
+    u = _ulps(got, want)
+    assert u.max() <= 1, f"{np.count_nonzero(u > 1)} values differ by more than one ulp (max {u.max()})"
+    print(f"count {count}: {np.count_nonzero(u)} of {u.size} values differ (by one ulp)")
+    assert np.count_nonzero(u) <= max(2, 0.05 * u.size)
+    for i, r in enumerate(refs):
+        _, key, pos, has, cached = r.get_state()
+        _, dkey, dpos, dhas, dcached = dn.state(i)
+        assert np.array_equal(key, dkey) and (pos, has) == (dpos, dhas)
+        assert _ulps(np.array([cached]), np.array([dcached])).max() <= 1
+    # the stream goes on: a second draw continues exactly where numpy continues (cache, block boundary, leftover words)
+    more = dn.draw(777)[0].cpu().numpy()
+    assert _ulps(more, np.stack([r.normal(size=777) for r in refs])).max() <= 1
+
+
+def test_device_normals_take_over_a_used_host_stream(dev):
+    """a stream handed over in the middle of a block, at a position that is not a multiple of an attempt's four words, with
+    a value in the cache: the device continues it like numpy would"""
+    from optimaltextures_amd.rotation import DeviceNormals
+    r = np.random.RandomState(99)
+    r.random_sample(3)          # 6 words: the position is now 2 mod 4
+    r.normal(size=5)            # odd count: one value sits in the cache
+    twin = np.random.RandomState(99)
+    twin.random_sample(3)
+    twin.normal(size=5)
+    dn = DeviceNormals(r, dev, side_stream=False)
+    got = np.concatenate([dn.draw(c)[0].cpu().numpy()[0] for c in (1, 4, 623, 2000)])
+    want = twin.normal(size=1 + 4 + 623 + 2000)
+    assert _ulps(got, want).max() <= 1
+    _, key, pos, has, _ = twin.get_state()
+    _, dkey, dpos, dhas, _ = dn.state(0)
+    assert np.array_equal(key, dkey) and (pos, has) == (dpos, dhas)
+
+
+@pytest.mark.parametrize("N,count", [(3, 5), (23, 4), (64, 3), (181, 2), (256, 2)])
+def test_device_stream_rotations_equal_host_stream_rotations(dev, N, count):
+    """rotations from the device-side stream vs the host-side numpy stream of the same seed: <= 1 ulp of fp32 apart (the bar of
+    the scipy goldens), one stream shared and one stream per texture; prefetched draws (side stream) equal on-demand ones"""
+    from optimaltextures_amd import rotation
+    from optimaltextures_amd.rotation import DeviceNormals
+    host = rotation.rotations(N, count, dev, rng=np.random.RandomState(31))[0].cpu().numpy()
+    dn = DeviceNormals(np.random.RandomState(31), dev)
+    dn.prefetch([(N, count), (N, 1)])
+    R32, Rt32 = dn.rotations(N, count)
+    torch.cuda.synchronize()
+    got = R32.cpu().numpy()
+    assert got.shape == host.shape and np.abs(got - host).max() <= 1.2e-7
+    assert np.array_equal(Rt32.cpu().numpy(), got.transpose(0, 2, 1))
+    assert np.mean(got == host) > 0.99
+    with pytest.raises(RuntimeError):
+        dn.rotations(N, 2)          # the prefetched draw was for ONE rotation
+    many = DeviceNormals([np.random.RandomState(31), np.random.RandomState(32)], dev)
+    R2 = many.rotations(N, count)[0].cpu().numpy()
+    assert R2.shape == (2, count, N, N) and np.abs(R2[0] - host).max() <= 1.2e-7
+    other = rotation.rotations(N, count, dev, rng=np.random.RandomState(32))[0].cpu().numpy()
+    assert np.abs(R2[1] - other).max() <= 1.2e-7
+
+
+def test_forward_with_device_rotation_stream_equals_host_stream(dev):
+    """OptimalTexture.forward with its rotations drawn on the GPU (prefetched for the whole call on a side stream) against the
+    same call with the numpy stream on the host: same seeds -> same rotations to 1 ulp of fp32 -> the same image to fp32
+    round-off in a smooth mode"""
+    from optimaltextures_amd.driver import OptimalTexture
+    from optimaltextures_amd.rotation import DeviceNormals
+    tex = OptimalTexture(size=128, iters=60, passes=2, hist_mode="chol", layers=(3, 2), independent=True).to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    style = torch.rand(1, 3, 96, 128, generator=g).to(dev)
+    noise = torch.rand(2, 3, 128, 128, generator=g).to(dev)
+    with torch.inference_mode():
+        tex.rng = np.random.RandomState(77)
+        a = tex.forward(noise.clone(), [style]).cpu().numpy()
+        tex.rng = DeviceNormals(np.random.RandomState(77), dev)
+        b = tex.forward(noise.clone(), [style]).cpu().numpy()
+        tex.rng = DeviceNormals([np.random.RandomState(77), np.random.RandomState(78)], dev)
+        c = tex.forward(noise.clone(), [style]).cpu().numpy()
+    assert np.abs(a - b).max() <= 2e-3 * np.abs(a).max(), np.abs(a - b).max()
+    # own streams: texture 0 keeps stream 77 (the same image), texture 1 follows stream 78 (another one)
+    assert np.abs(c[0] - a[0]).max() <= 2e-3 * np.abs(a).max() and np.abs(c[1] - a[1]).max() > 1e-2
+
+
 # ================================================================================================ full-size (BASELINE) properties
 def test_full_size_relu3_1_step_vs_oracle(dev):
     """BASELINE config shape: relu3_1 at the 512 pass, C = 256, n = 128*128, style 128x96 — one whole cdf step bit-exact
