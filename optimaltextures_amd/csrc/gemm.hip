@@ -518,7 +518,16 @@ static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     // 64 < M <= 256, 64 <= K <= 256: PCA ranks (M = K = 181: 86 vs 60 TFLOP/s of useful flops), project / unproject
     // (181 x 256: 93 vs 67), 192 x 192 (89 vs 78), relu2_1's ranks (k ~ 84 of C = 128).
     if (!BPM && !OPM && gemm_rs_enabled && gemm_rs_supported(a, n_cu)) {
-        const bool lds_fits = a.M > 192 && a.K > 192 && a.M % 4 == 0 && vec && a.a_vec && hot_shape(a, n_cu) && output_vec(a);
+        bool lds_fits = a.M > 192 && a.K > 192 && a.M % 4 == 0 && vec && a.a_vec && hot_shape(a, n_cu) && output_vec(a);
+        if (lds_fits) {
+            // Small batches (BASELINE config 4 shards 8 textures per GPU): a launch is a handful of 128-pixel tiles per CU
+            // and its time is the LARGEST number of tiles a CU gets — 576 tiles on 256 CUs take as long as 768.  The
+            // R-stationary kernel cuts the map into 64-pixel tiles: where that rounds markedly better (it is ~4 % behind at
+            // steady state) it takes the launch.  Both kernels give the same bits.
+            auto filled = [n_cu](long long tiles) { return (double)tiles / (double)(((tiles + n_cu - 1) / n_cu) * n_cu); };
+            const long long t128 = (long long)(a.n / 128) * a.n_seg, t64 = (long long)(a.n / 64) * a.n_seg;
+            if (filled(t64) >= filled(t128) + 0.06) lds_fits = false;
+        }
         if (!lds_fits || gemm_rs_force) return gemm_rs_launch(a, n_cu, st);
     }
     if (big >= 2LL * n_cu && a.M > 64) {
