@@ -167,6 +167,9 @@ size_t optex_rotation_ws_bytes(int N, int count);
  * exact; every floating-point operation is the host's IEEE operation except log(), which is correctly rounded here and
  * 0.52-ulp accurate in glibc: >= 99.8 % of the values equal numpy's bit for bit, the rest differ by a few ulp. */
 size_t optex_mt19937_state_bytes(void);
+/* states of n_streams streams as numpy's RandomState(seed) leaves them for the 32-bit integer seeds first_seed + s * seed_stride
+ * (mod 2^32): init_genrand, position 624, cache empty — no host transfer. */
+int optex_mt19937_seed(void* states, int n_streams, uint32_t first_seed, uint32_t seed_stride, void* stream);
 int optex_legacy_normals(void* states, int n_streams, long count, double* out, long out_stride, void* stream);
 int optex_rotations_from_normals(const double* normals, int N, int count, double* R64, float* R32, float* Rt32,
                                  void* ws, size_t ws_bytes, void* stream);

@@ -123,7 +123,8 @@ ProfScope::~ProfScope() {
 
 static const char* kClassNames[KC_COUNT] = {"gemm_tn", "col_minmax", "col_hist", "cdf_lut", "cdf_apply", "sort_columns",
                                             "sort_match", "col_mean", "gram", "cov_finalize", "householder", "interp",
-                                            "sort_radix_sweep", "vgg_glue", "linalg_gemm", "chol_inv", "ns_init"};
+                                            "sort_radix_sweep", "vgg_glue", "linalg_gemm", "chol_inv", "ns_init",
+                                            "legacy_normals"};
 
 }  // namespace optex
 

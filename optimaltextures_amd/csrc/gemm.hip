@@ -44,8 +44,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     const bool sym = !OPM && !BPM && BM == BN && a.sym;
     if (sym && (long)m0 > n0) return;  // the mirror image of a tile above the diagonal (uniform for the block)
 
-    const float* __restrict__ At = a.At + (size_t)seg * a.at_ss;
-    const float* __restrict__ Bp = a.B + (size_t)seg * a.b_ss;
+    // (second operand set of a two-batch launch: uniform for the block)
+    const bool second = a.half > 0 && seg >= a.half;
+    const int oseg = second ? seg - a.half : seg;
+    const float* __restrict__ At = (second ? a.At2 : a.At) + (size_t)oseg * a.at_ss;
+    const float* __restrict__ Bp = (second ? a.B2 : a.B) + (size_t)oseg * a.b_ss;
     const float* __restrict__ bsub = a.bsub ? a.bsub + (size_t)seg * a.bsub_ss : nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,12 +185,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_tn_kernel(GemmArgs a) {
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    float* __restrict__ Op = a.O + (size_t)seg * a.o_ss;
+    float* __restrict__ Op = (second ? a.O2 : a.O) + (size_t)oseg * a.o_ss;
     const float* __restrict__ Cp = a.content ? a.content + (size_t)seg * a.o_ss : nullptr;
     const float* __restrict__ badd = a.badd ? a.badd + (size_t)seg * a.badd_ss : nullptr;
     const float strength = a.strength;
     const bool epi = a.epi;
-    const float alpha = epi ? (a.alpha_seg ? a.alpha * a.alpha_seg[seg] : a.alpha) : 1.f;
+    const float* aseg = second ? a.alpha_seg2 : a.alpha_seg;
+    const float alpha = epi ? (aseg ? a.alpha * aseg[oseg] : a.alpha) : 1.f;
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
         const int mb = m0 + wm * WM + tm * 32 + 4 * h;

@@ -31,6 +31,10 @@ struct GemmArgs {
     // optional device-side switch of a launch that was enqueued before anyone knew whether it is needed (the later
     // Newton-Schulz iterations of linalg.hip): the kernel returns at once if live_idx >= *live_until.  gemm_tn_kernel only.
     const int* live_until = nullptr; int live_idx = 0;
+    // optional second operand set (gemm_tn_kernel only): segments half .. n_seg - 1 run At2 / B2 -> O2 (same shapes, strides and
+    // epilogue, scaled by alpha_seg2) — two independent batches of products in ONE launch (the Y W and W Z of a Newton-Schulz
+    // iteration, linalg.hip).  half = 0: off.
+    int half = 0; const float* At2 = nullptr; const float* B2 = nullptr; float* O2 = nullptr; const float* alpha_seg2 = nullptr;
 };
 
 // the launch of `a` (channel-major in and out) takes the hot-loop kernel, i.e. a.rowstat is honoured

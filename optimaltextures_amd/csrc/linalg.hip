@@ -360,6 +360,26 @@ int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O
     return gemm_tn_launch(a, OPTEX_PIXEL_MAJOR, OPTEX_PIXEL_MAJOR, st);
 }
 
+// Two independent batches of true products in ONE launch:  O1[b] = alpha alpha1[b] (A1[b] B1[b]),  O2[b] = alpha alpha2[b]
+// (A2[b] B2[b]),  b < batch — the Y W and W Z of a Newton-Schulz iteration (3 800 launches per sym-mode step were 2 500 of
+// these pairs going out one by one).
+int small_gemm_nn_pair(const float* A1, const float* B1, float* O1, const float* alpha1, const float* A2, const float* B2, float* O2,
+                       const float* alpha2, int C, int batch, float alpha, const int* live_until, int live_idx, hipStream_t st) {
+    const long cc = (long)C * C;
+    GemmArgs a;
+    a.At = B1; a.lda = C; a.at_ss = cc;
+    a.B = A1; a.ldb = C; a.b_ss = cc;
+    a.O = O1; a.ldo = C; a.o_ss = cc;
+    a.M = C; a.K = C; a.n = C; a.n_seg = 2 * batch;
+    a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
+    a.epi = 1; a.alpha = alpha; a.alpha_seg = alpha1; a.diag = 0.f; a.sym = 0;
+    a.prof_cls = KC_SMALL_GEMM;
+    a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
+    a.live_until = live_until; a.live_idx = live_idx;
+    a.half = batch; a.At2 = B2; a.B2 = A2; a.O2 = O2; a.alpha_seg2 = alpha2;
+    return gemm_tn_launch(a, OPTEX_PIXEL_MAJOR, OPTEX_PIXEL_MAJOR, st);
+}
+
 // lower end of the spectrum of Z0 Y0 = A / |A|_F; without a bound from the caller: fp32 cannot resolve eigenvalues below
 // ~2^-23 |A|_F anyway
 __device__ __forceinline__ double ns_l0(float lambda_min, double fro) {
@@ -492,8 +512,7 @@ int ns_sqrt(const float* A, long a_ss, int C, int batch, float lambda_min, float
     for (int k = 0; k < K; k++) {
         const size_t o = (size_t)k * batch;
         if ((rc = small_gemm_nn(Z, (long)cc, Y, (long)cc, W, C, batch, -0.5f, cw + o, 1.5f, k_need, k, st))) return rc;   // W = 1.5 I - 0.5 a^2 Z Y
-        if ((rc = small_gemm_nn(Y, (long)cc, W, (long)cc, Y2, C, batch, 1.f, cy + o, 0.f, k_need, k, st))) return rc;     // Y <- a Y W
-        if ((rc = small_gemm_nn(W, (long)cc, Z, (long)cc, Z2, C, batch, 1.f, cz + o, 0.f, k_need, k, st))) return rc;     // Z <- a W Z
+        if ((rc = small_gemm_nn_pair(Y, W, Y2, cy + o, W, Z, Z2, cz + o, C, batch, 1.f, k_need, k, st))) return rc;        // Y <- a Y W, Z <- a W Z
         float* t = Y; Y = Y2; Y2 = t;
         t = Z; Z = Z2; Z2 = t;
     }

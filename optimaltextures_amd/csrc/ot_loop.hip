@@ -35,6 +35,12 @@ enum { MODE_CDF = 0, MODE_SORT = 1, MODE_CHOL = 2, MODE_PCA = 3, MODE_SYM = 4 };
 constexpr size_t kHoistBytes = (size_t)1 << 30;  // rotated style copies of all iterations of a call: at most 1 GiB
 constexpr float kEps = 1.0f;  // histmatch.py:5 `eps: float = 1`; no caller overrides it (optex.py:173,200-201)
 
+// Leading dimension of the rotated scratch map of the linear modes.  The Gram kernel stages eight rows of a pixel chunk per
+// wave: with rows exactly 64 KiB apart (n = 16384, the 512^2 pass of relu3_1) every row of a staged chunk sits on the same
+// memory channel and the kernel loses 17 % (727 us against 604 / 618 us at n = 16352 / 16416, profiles/r03_gram_kernels.md).
+// The map is scratch of this file: its rows simply get 256 bytes further apart.
+long padded_ld(long n) { return (n * (long)sizeof(float)) % 65536 == 0 ? n + 64 : n; }
+
 // bump allocator over the caller's scratch; with base == nullptr it only measures
 struct Bump {
     char* base;
@@ -114,7 +120,7 @@ struct LoopWs {
         const size_t pp = (size_t)NP * NP;
         const size_t nb = NS > (size_t)n_seg ? NS : (size_t)n_seg;
         if (fused == 0) {         // default: rotate, then apply + rotate back as one GEMM
-            y = b.take<float>(xs);
+            y = b.take<float>((size_t)n_seg * C * padded_ld(n));
             M1 = b.take<float>((size_t)n_seg * cc);
             if (rs_parts) rs_a = b.take<float>(rs_floats);
         } else if (fused == 2) {  // literal three-GEMM sequence
@@ -163,20 +169,23 @@ int copy_async(float* dst, const float* src, size_t count, hipStream_t st) { ret
 
 // feature-map GEMM with every option spelled out (the C ABI entry point with the loop's fixed layouts)
 int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, int n_seg, const float* bsub, const float* badd,
-          long badd_ss, const float* content, float strength, void* stream) {
+          long badd_ss, const float* content, float strength, void* stream, long ldb = 0) {
     const long xs = (long)C * n;
-    return optex_gemm_tn(At, C, at_ss, B, n, xs, OPTEX_CHANNEL_MAJOR, O, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, bsub, C,
-                         badd, badd_ss, content, strength, stream);
+    if (ldb == 0) ldb = n;
+    return optex_gemm_tn(At, C, at_ss, B, ldb, (long)C * ldb, OPTEX_CHANNEL_MAJOR, O, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, bsub,
+                         C, badd, badd_ss, content, strength, stream);
 }
+
 
 // optex.py:170  rotated = feature @ rotation  on the loop's layouts, with the per-row statistics of the result taken in the
 // GEMM's epilogue when the launch takes the hot-loop kernel (rowstat 1 = min / max, 2 = sums; *took says whether it did)
 int rotate_with_stats(const float* R, long r_ss, const float* x, float* y, int C, long n, int n_seg, int rowstat, float* rs_a,
-                      float* rs_b, bool* took, hipStream_t st) {
+                      float* rs_b, bool* took, hipStream_t st, long ldy = 0) {
+    if (ldy == 0) ldy = n;
     GemmArgs a;
     a.At = R; a.lda = C; a.at_ss = r_ss;
     a.B = x; a.ldb = n; a.b_ss = (long)C * n;
-    a.O = y; a.ldo = n; a.o_ss = (long)C * n;
+    a.O = y; a.ldo = ldy; a.o_ss = (long)C * ldy;
     a.M = C; a.K = C; a.n = n; a.n_seg = n_seg;
     a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
     a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.sym = 0; a.prof_cls = KC_GEMM;
@@ -312,10 +321,11 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
         if (fused == 0) {
             // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (+ the row sums for the means, in the epilogue)
             bool sums = false;
-            if ((rc = rotate_with_stats(R, r_ss, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st))) return rc;
+            const long ldy = padded_ld(n);
+            if ((rc = rotate_with_stats(R, r_ss, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st, ldy))) return rc;
             // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I   (statistics of the ROTATED map, like the reference)
-            if ((rc = linear_stats_parts(w.y, n, xs, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws, w.stats_ws_bytes,
-                                         sums ? w.rs_a : nullptr, w.rs_parts, stream)))
+            if ((rc = linear_stats_parts(w.y, ldy, (long)C * ldy, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws,
+                                         w.stats_ws_bytes, sums ? w.rs_a : nullptr, w.rs_parts, stream)))
                 return rc;
             if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, G, it, st))) return rc;   // At = T^T
             // histmatch.py:27/34/42,44 + optex.py:175, 115-117:  (T hist_t + mu_sr) @ R^T  evaluated as ONE feature-map GEMM
@@ -323,7 +333,7 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
             // — the same product in another association (a C x C GEMM instead of a second C x n one); the content blend
             // rides in the epilogue as before.
             if ((rc = small_gemm_nn(w.At, (long)cc, Rt, r_ss, w.M1, C, n_seg, 1.f, nullptr, 0.f, nullptr, 0, st))) return rc;
-            if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream)))
+            if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream, ldy)))
                 return rc;
         } else if (fused == 2) {
             // the literal sequence, three feature-map GEMMs (kept for tests and comparisons)

@@ -132,12 +132,13 @@ __device__ __forceinline__ dd2 dd_mul(dd2 x, dd2 y) {
     const double e = __builtin_fma(x.h, y.h, -p) + (x.h * y.l + x.l * y.h);
     return dd_fast(p, e);
 }
-__device__ __forceinline__ dd2 dd_div(dd2 x, dd2 y) {
-    const double q1 = x.h / y.h;
+__device__ __forceinline__ dd2 dd_div(dd2 x, dd2 y) {   // three quotient digits; each remainder is exact to double-double
+    const double inv = 1.0 / y.h;
+    const double q1 = x.h * inv;
     dd2 r = dd_add(x, dd_mul(y, dd2{-q1, 0.0}));
-    const double q2 = r.h / y.h;
+    const double q2 = r.h * inv;
     r = dd_add(r, dd_mul(y, dd2{-q2, 0.0}));
-    const double q3 = r.h / y.h;
+    const double q3 = r.h * inv;
     return dd_add(dd_fast(q1, q2), dd2{q3, 0.0});
 }
 
@@ -183,7 +184,7 @@ __device__ double log_unit_interval(double x) {
 }
 
 __device__ __forceinline__ double mt_unit(uint32_t w0, uint32_t w1) {
-    return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
+    return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);   // (a power of two: exact)
 }
 
 __global__ __launch_bounds__(256) void legacy_normals_kernel(uint32_t* __restrict__ states, long count, double* __restrict__ out,
@@ -288,9 +289,37 @@ __global__ __launch_bounds__(256) void legacy_normals_kernel(uint32_t* __restric
     }
 }
 
+// numpy's RandomState(seed) for a 32-bit integer seed (mt19937_seed / Knuth's init_genrand): key[0] = seed,
+// key[i] = 1812433253 (key[i-1] ^ key[i-1] >> 30) + i;  pos = 624 (the first draw regenerates the block), cache empty.
+// One lane per stream: 623 dependent steps, a few microseconds.
+__global__ void mt_seed_kernel(uint32_t* __restrict__ states, int n_streams, uint32_t first_seed, uint32_t seed_stride) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    uint32_t* st = states + (size_t)s * MT_STATE_WORDS;
+    uint32_t v = first_seed + seed_stride * (uint32_t)s;
+    for (int i = 0; i < MT_N; i++) {
+        st[i] = v;
+        v = 1812433253u * (v ^ (v >> 30)) + (uint32_t)i + 1u;
+    }
+    st[MT_N] = (uint32_t)MT_N;
+    st[MT_N + 1] = 0u;
+    st[MT_N + 2] = 0u;
+    st[MT_N + 3] = 0u;
+}
+
 }  // namespace optex
 
 using namespace optex;
+
+extern "C" int optex_mt19937_seed(void* states, int n_streams, uint32_t first_seed, uint32_t seed_stride, void* stream) {
+    if (!states || n_streams <= 0) {
+        set_error("optex_mt19937_seed: bad argument (n_streams=%d)", n_streams);
+        return OPTEX_E_ARG;
+    }
+    hipLaunchKernelGGL(mt_seed_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, as_stream(stream), static_cast<uint32_t*>(states),
+                       n_streams, first_seed, seed_stride);
+    return check_launch("mt_seed_kernel");
+}
 
 extern "C" size_t optex_mt19937_state_bytes(void) { return (size_t)MT_STATE_WORDS * sizeof(uint32_t); }
 
@@ -301,7 +330,7 @@ extern "C" int optex_legacy_normals(void* states, int n_streams, long count, dou
     }
     if (count == 0) return OPTEX_OK;
     hipStream_t st = as_stream(stream);
-    ProfScope prof(KC_ROTGEN, st, 0.0, 8.0 * (double)count * n_streams);
+    ProfScope prof(KC_NORMALS, st, 0.0, 8.0 * (double)count * n_streams);
     hipLaunchKernelGGL(legacy_normals_kernel, dim3(n_streams), dim3(256), 0, st, static_cast<uint32_t*>(states), count, out,
                        out_stride);
     return check_launch("legacy_normals_kernel");

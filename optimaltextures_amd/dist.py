@@ -261,7 +261,7 @@ def rotation_stream(seed: int, groups, device):
     (one sequence shared by its textures) or a list of them (one sequence per texture, group size 1)"""
     from .rotation import DeviceNormals
     many = isinstance(groups, (list, tuple, range))
-    return DeviceNormals([rotation_rng(seed, g) for g in (groups if many else [groups])], device)
+    return DeviceNormals([rotation_seed(seed, g) for g in (groups if many else [groups])], device)   # seeded on the device
 
 
 def barrier():

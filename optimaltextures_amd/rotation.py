@@ -68,23 +68,35 @@ class DeviceNormals:
     convolutions and the OT loops find their rotations ready."""
 
     def __init__(self, rngs, device, side_stream: bool = True):
+        """rngs: one or a list of numpy RandomState objects (their current state is taken over) or 32-bit integer seeds
+        (RandomState(seed), seeded on the device: nothing crosses the bus)"""
         rngs = list(rngs) if isinstance(rngs, (list, tuple)) else [rngs]
-        words = _lib.load().optex_mt19937_state_bytes() // 4
-        host = np.zeros((len(rngs), words), dtype=np.uint32)
-        for i, r in enumerate(rngs):
-            if not isinstance(r, np.random.RandomState):
-                r = np.random.RandomState(int(r))
-            name, key, pos, has_gauss, cached = r.get_state()
-            assert name == "MT19937" and key.shape == (624,)
-            host[i, :624] = key
-            host[i, 624] = pos
-            host[i, 625] = has_gauss
-            host[i, 626:628] = np.frombuffer(np.float64(cached).tobytes(), dtype=np.uint32)
+        lib = _lib.lib()
+        words = lib.optex_mt19937_state_bytes() // 4
         self.device = torch.device(device)
         self.n = len(rngs)
-        self.states = torch.from_numpy(host.view(np.int32)).to(self.device)
         self.stream = torch.cuda.Stream(self.device) if side_stream else None
         self._queue = deque()   # prefetched draws in stream order: (N, count, normals, event)
+        run = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        ints = all(isinstance(r, (int, np.integer)) and 0 <= int(r) < 2 ** 32 for r in rngs)
+        stride = (int(rngs[1]) - int(rngs[0])) % 2 ** 32 if ints and self.n > 1 else 0
+        with torch.cuda.stream(run):
+            self.states = torch.empty((self.n, words), dtype=torch.int32, device=self.device)
+            if ints and all((int(rngs[0]) + i * stride) % 2 ** 32 == int(r) for i, r in enumerate(rngs)):
+                _lib.check(lib.optex_mt19937_seed(_lib.ptr(self.states), self.n, int(rngs[0]), stride, ctypes_stream(run)))
+                return
+            host = torch.empty((self.n, words), dtype=torch.int32).pin_memory()   # (torch caches pinned blocks)
+            hv = host.numpy().view(np.uint32)
+            for i, r in enumerate(rngs):
+                if not isinstance(r, np.random.RandomState):
+                    r = np.random.RandomState(int(r))
+                name, key, pos, has_gauss, cached = r.get_state()
+                assert name == "MT19937" and key.shape == (624,)
+                hv[i, :624] = key
+                hv[i, 624] = pos
+                hv[i, 625] = has_gauss
+                hv[i, 626:628] = np.frombuffer(np.float64(cached).tobytes(), dtype=np.uint32)
+            self.states.copy_(host, non_blocking=True)   # asynchronous, on the generator's stream: the host does not wait
 
     def state(self, i: int = 0):
         """the stream's state as numpy's get_state() tuple (a host synchronisation: tests, hand-over back to the host)"""

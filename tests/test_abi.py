@@ -62,6 +62,7 @@ def test_round4_entry_points_check_their_arguments_without_launching():
     assert lib.optex_legacy_normals(p, 1, 10, p, 5, None) == -1      # out_stride smaller than count
     assert lib.optex_legacy_normals(p, 0, 10, p, 10, None) == -1
     assert lib.optex_legacy_normals(p, 1, 0, p, 0, None) == 0        # nothing to draw: no launch
+    assert lib.optex_mt19937_seed(None, 1, 5, 1, None) == -1 and lib.optex_mt19937_seed(p, 0, 5, 1, None) == -1
 
 
 def test_round3_entry_points_check_their_arguments_without_launching():

@@ -892,6 +892,23 @@ def test_device_normals_follow_numpy_stream(dev, count):
     assert u2.max() <= 4 and np.count_nonzero(u2) <= 5
 
 
+def test_device_seeding_equals_numpy_seeding(dev):
+    """optex_mt19937_seed: RandomState(seed) for integer seeds, seeded on the device (bench.py's streams never cross the bus):
+    the key words, the position and the first values are numpy's"""
+    from optimaltextures_amd.rotation import DeviceNormals
+    seeds = [2 ** 32 - 2, 2 ** 32 - 1, 0, 1]           # consecutive mod 2^32: the strided seeding path
+    dn = DeviceNormals(seeds, dev, side_stream=False)
+    for i, sd in enumerate(seeds):
+        _, key, pos, has, cached = np.random.RandomState(sd).get_state()
+        _, dkey, dpos, dhas, dcached = dn.state(i)
+        assert np.array_equal(key, dkey) and (pos, has, cached) == (dpos, dhas, dcached)
+    got = dn.draw(501)[0].cpu().numpy()
+    want = np.stack([np.random.RandomState(sd).normal(size=501) for sd in seeds])
+    assert _ulps(got, want).max() <= 4 and np.count_nonzero(_ulps(got, want)) <= 4
+    scattered = DeviceNormals([5, 1000, 17], dev, side_stream=False)   # no common stride: states built on the host, pinned copy
+    assert np.array_equal(scattered.state(1)[1], np.random.RandomState(1000).get_state()[1])
+
+
 def test_device_normals_take_over_a_used_host_stream(dev):
     """a stream handed over in the middle of a block, at a position that is not a multiple of an attempt's four words, with
     a value in the cache: the device continues it like numpy would"""
