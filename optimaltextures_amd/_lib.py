@@ -42,7 +42,8 @@ SIGNATURES = {
     "optex_rotation_ws_bytes": (_SZ, [_I, _I]),
     "optex_mt19937_state_bytes": (_SZ, []),
     "optex_mt19937_seed": (_I, [_P, _I, _c.c_uint32, _c.c_uint32, _P]),
-    "optex_legacy_normals": (_I, [_P, _I, _L, _P, _L, _P]),
+    "optex_legacy_normals_ws_bytes": (_SZ, [_I, _L]),
+    "optex_legacy_normals": (_I, [_P, _I, _L, _P, _L, _P, _SZ, _P]),
     "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "optex_ot_loop_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I, _L]),
     "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _L, _I, _P, _F, _I, _P, _SZ, _P]),

@@ -87,9 +87,10 @@ __global__ __launch_bounds__(64) void householder_apply_kernel(const double* __r
 // Sequential as written, parallel in fact: an ATTEMPT always consumes exactly four 32-bit words whether it is accepted or
 // not, so attempt j of a stretch of the stream is a pure function of words 4j .. 4j + 3, and the outputs are the accepted
 // attempts in order (a prefix sum of the accept flags).  The MT19937 recurrence x[k + 624] = x[k + 397] ^ t(x[k], x[k + 1])
-// is itself parallel 227 wide.  One workgroup of 256 threads per stream: per round it regenerates the 624-word block in
-// three 227-wide phases (out of place: no read-before-write hazards), tempers it, evaluates the <= 157 attempts of the
-// block in parallel and writes the accepted pairs behind each other.  State in / out: 624 key words, the position inside the
+// is itself parallel 227 wide.  Two stages: one WAVEFRONT per stream regenerates the 624-word blocks (three 227-wide phases, out
+// of place: no read-before-write hazards), tempers them, takes the accept / reject decisions of a block's <= 157 attempts
+// 64 at a time and writes the accepted (x1, x2, r2) behind each other; then one thread per accepted pair, on all CUs, does
+// the expensive part (the logarithm).  State in / out: 624 key words, the position inside the
 // block, the cache flag and the cached value — numpy's RandomState.get_state() tuple, so a stream can be handed over
 // from / to the host at any point.  Every operation is IEEE (no contraction, correctly rounded division and square root)
 // and identical to the host's, except log(): log_unit_interval below is correctly rounded, glibc's log is accurate to
@@ -187,106 +188,132 @@ __device__ __forceinline__ double mt_unit(uint32_t w0, uint32_t w1) {
     return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);   // (a power of two: exact)
 }
 
-__global__ __launch_bounds__(256) void legacy_normals_kernel(uint32_t* __restrict__ states, long count, double* __restrict__ out,
-                                                             long out_stride) {
+// Stage 1, ONE WAVEFRONT per stream (the only sequential part): the MT19937 words and the accept / reject decisions.
+// Accepted attempts leave (x1, x2, r2) behind each other in `pairs`; the stream stops exactly behind the attempt that
+// completes the draw, so the state handed back is numpy's.  A single wavefront needs no workgroup barrier (the
+// __syncthreads() of a 64-thread block only orders its own LDS traffic) and shares its CU with whatever else runs there
+// at the cost of one wave slot: a whole bench step's 1.7 M normals take ~3 ms of one SIMD, beside the convolutions.
+struct NormalsMeta { long npairs; long lead; double cached; long pad; };   // per stream: pairs written, 1 if out[0] is the old cache
+
+__global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ states, long count, double* __restrict__ pairs,
+                                                       long pairs_stride, NormalsMeta* __restrict__ meta) {
     __shared__ uint32_t key[2][MT_N];   // the block, ping-pong
     __shared__ uint32_t sw[MT_N + 4];   // tempered words still to be consumed: <= 3 carried over + the rest of the block
-    __shared__ uint32_t wtot[4];
     __shared__ int s_stop;
-    __shared__ double s_cache;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     uint32_t* st = states + (size_t)blockIdx.x * MT_STATE_WORDS;
-    double* o = out + (size_t)blockIdx.x * out_stride;
-    for (int i = tid; i < MT_N; i += 256) key[0][i] = st[i];
-    // uniform bookkeeping: block in use, position inside it, words carried over, values delivered, cache state
-    int cur = 0, pos = (int)st[MT_N], carry = 0, has = (int)st[MT_N + 1];
+    double* pr = pairs + (size_t)blockIdx.x * pairs_stride;
+    for (int i = lane; i < MT_N; i += 64) key[0][i] = st[i];
+    // uniform bookkeeping: block in use, position inside it, words carried over, pairs delivered
+    int cur = 0, pos = (int)st[MT_N], carry = 0;
+    const int had = (int)st[MT_N + 1];
+    const long lead = (count > 0 && had) ? 1 : 0;          // the cached second value of the last pair goes out first
+    const long need = count - lead;                          // values to come from new pairs
+    const long want = (need + 1) / 2;                        // pairs
     long done = 0;
-    if (tid == 0) s_cache = *reinterpret_cast<const double*>(st + MT_N + 2);
-    __syncthreads();
-    if (count > 0 && has) {   // the cached second value of the last accepted pair goes out first
-        if (tid == 0) o[0] = s_cache;
-        done = 1;
-        has = 0;
+    if (lane == 0) {
+        NormalsMeta m;
+        m.npairs = want;
+        m.lead = lead;
+        m.cached = *reinterpret_cast<const double*>(st + MT_N + 2);
+        m.pad = 0;
+        meta[blockIdx.x] = m;
     }
-    while (done < count) {
+    __syncthreads();
+    constexpr int W = MT_N - MT_M;  // 227: the recurrence is W wide
+    while (done < want) {
         if (pos >= MT_N) {
             // next block, out of place: key[cur] -> key[cur ^ 1], three phases of up to 227 independent words
             const uint32_t* a = key[cur];
             uint32_t* b = key[cur ^ 1];
-            constexpr int W = MT_N - MT_M;  // 227
-            if (tid < W) b[tid] = mt_twist(a[tid], a[tid + 1], a[tid + MT_M]);
+            for (int k = lane; k < W; k += 64) b[k] = mt_twist(a[k], a[k + 1], a[k + MT_M]);
             __syncthreads();
-            if (tid < W) b[tid + W] = mt_twist(a[tid + W], a[tid + W + 1], b[tid]);
+            for (int k = lane; k < W; k += 64) b[k + W] = mt_twist(a[k + W], a[k + W + 1], b[k]);
             __syncthreads();
-            if (tid < MT_N - 2 * W) {
-                const int k = tid + 2 * W;
-                b[k] = mt_twist(a[k], k + 1 < MT_N ? a[k + 1] : b[0], b[k - W]);
-            }
+            for (int k = 2 * W + lane; k < MT_N; k += 64) b[k] = mt_twist(a[k], k + 1 < MT_N ? a[k + 1] : b[0], b[k - W]);
             __syncthreads();
             cur ^= 1;
             pos = 0;
         }
         // the rest of the block, tempered, behind the words carried over from the last one
         const int avail = MT_N - pos, total = carry + avail, nat = total >> 2;
-        for (int i = tid; i < avail; i += 256) sw[carry + i] = mt_temper(key[cur][pos + i]);
+        for (int i = lane; i < avail; i += 64) sw[carry + i] = mt_temper(key[cur][pos + i]);
         __syncthreads();
-        bool acc = false;
-        double v2 = 0.0, v1 = 0.0;
-        if (tid < nat) {
-            const double x1 = 2.0 * mt_unit(sw[4 * tid], sw[4 * tid + 1]) - 1.0;
-            const double x2 = 2.0 * mt_unit(sw[4 * tid + 2], sw[4 * tid + 3]) - 1.0;
-            const double r2 = x1 * x1 + x2 * x2;
-            acc = !(r2 >= 1.0 || r2 == 0.0);
-            if (acc) {
-                const double f = sqrt(-2.0 * log_unit_interval(r2) / r2);
-                v2 = f * x2;
-                v1 = f * x1;
+        bool stopped = false;
+        for (int j0 = 0; j0 < nat && !stopped; j0 += 64) {   // 64 attempts at a time, in order
+            const int j = j0 + lane;
+            bool acc = false;
+            double x1 = 0.0, x2 = 0.0, r2 = 0.0;
+            if (j < nat) {
+                x1 = 2.0 * mt_unit(sw[4 * j], sw[4 * j + 1]) - 1.0;
+                x2 = 2.0 * mt_unit(sw[4 * j + 2], sw[4 * j + 3]) - 1.0;
+                r2 = x1 * x1 + x2 * x2;
+                acc = !(r2 >= 1.0 || r2 == 0.0);
+            }
+            const unsigned long long bal = __ballot(acc);
+            const long before = (long)__popcll(bal & ((1ull << lane) - 1ull));   // accepted attempts in front of mine
+            const long accepted = (long)__popcll(bal), room = want - done;
+            if (acc && before < room) {
+                double* p = pr + 3 * (done + before);
+                p[0] = x1;
+                p[1] = x2;
+                p[2] = r2;
+            }
+            if (accepted >= room) {
+                // the stream stops behind the attempt that delivers pair number want - 1: the words after it stay unconsumed
+                if (acc && before == room - 1) s_stop = j;
+                __syncthreads();
+                pos += 4 * (s_stop + 1) - carry;   // words of THIS block consumed from pos on (the carried ones were the last block's)
+                carry = 0;
+                done = want;
+                stopped = true;
+            } else {
+                done += accepted;
             }
         }
-        const unsigned long long bal = __ballot(acc);
-        if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        long before = (long)__popcll(bal & ((1ull << lane) - 1ull));   // accepted attempts in front of mine
-        for (int k = 0; k < wave; k++) before += wtot[k];
-        const long accepted = (long)wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        const long room = count - done;   // values still wanted
-        // accepted attempt number `before` delivers values 2 * before and 2 * before + 1 of this round
-        if (acc && 2 * before < room) {
-            o[done + 2 * before] = v2;
-            if (2 * before + 1 < room) o[done + 2 * before + 1] = v1;
-        }
-        if (2 * accepted >= room) {
-            // The stream stops inside this round, behind the attempt that delivers value number room - 1: the words after
-            // it stay unconsumed, and an odd `room` leaves that attempt's second value in the cache.
-            if (acc && before == (room - 1) / 2) {
-                s_stop = tid;
-                s_cache = v1;
-            }
-            __syncthreads();
-            pos += 4 * (s_stop + 1) - carry;   // words of THIS block consumed from pos on (the carried ones were the last block's)
-            carry = 0;
-            has = (int)(room & 1);
-            done = count;
-        } else {
-            done += 2 * accepted;
+        if (!stopped) {
             const int left = total - 4 * nat;  // up to three words are left over: they open the next round
             uint32_t keep = 0u;
-            if (tid < left) keep = sw[4 * nat + tid];
+            if (lane < left) keep = sw[4 * nat + lane];
             __syncthreads();
-            if (tid < left) sw[tid] = keep;
+            if (lane < left) sw[lane] = keep;
             carry = left;
             pos = MT_N;
-            has = 0;
+        }
+        __syncthreads();
+    }
+    // hand the state back (the loop leaves through its stop branch: nothing is carried over here).  An odd number of new
+    // values leaves the second value of the last pair in the cache: stage 2 knows it and stores it (state word 626).
+    for (int i = lane; i < MT_N; i += 64) st[i] = key[cur][i];
+    if (lane == 0) {
+        st[MT_N] = (uint32_t)pos;
+        if (count > 0) {
+            st[MT_N + 1] = (uint32_t)(need & 1);
+            if (!(need & 1)) {
+                st[MT_N + 2] = 0u;
+                st[MT_N + 3] = 0u;
+            }
         }
     }
-    __syncthreads();
-    // hand the state back (the loop leaves through its stop branch: nothing is carried over here)
-    for (int i = tid; i < MT_N; i += 256) st[i] = key[cur][i];
-    if (tid == 0) {
-        st[MT_N] = (uint32_t)pos;
-        st[MT_N + 1] = (uint32_t)has;
-        *reinterpret_cast<double*>(st + MT_N + 2) = has ? s_cache : 0.0;
-    }
+}
+
+// Stage 2, one thread per accepted pair, all CUs: f = sqrt(-2 log(r2) / r2), values f x2 and f x1 in that order
+__global__ __launch_bounds__(256) void normals_emit_kernel(uint32_t* __restrict__ states, long count, const double* __restrict__ pairs,
+                                                           long pairs_stride, const NormalsMeta* __restrict__ meta,
+                                                           double* __restrict__ out, long out_stride) {
+    const int s = blockIdx.y;
+    const NormalsMeta m = meta[s];
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    double* o = out + (size_t)s * out_stride;
+    if (r == 0 && m.lead) o[0] = m.cached;
+    if (r >= m.npairs) return;
+    const double* p = pairs + (size_t)s * pairs_stride + 3 * r;
+    const double x1 = p[0], x2 = p[1], r2 = p[2];
+    const double f = sqrt(-2.0 * log_unit_interval(r2) / r2);
+    const long at = m.lead + 2 * r;
+    o[at] = f * x2;
+    if (at + 1 < count) o[at + 1] = f * x1;
+    else *reinterpret_cast<double*>(states + (size_t)s * MT_STATE_WORDS + MT_N + 2) = f * x1;   // the draw ends on a first value
 }
 
 // numpy's RandomState(seed) for a 32-bit integer seed (mt19937_seed / Knuth's init_genrand): key[0] = seed,
@@ -323,17 +350,32 @@ extern "C" int optex_mt19937_seed(void* states, int n_streams, uint32_t first_se
 
 extern "C" size_t optex_mt19937_state_bytes(void) { return (size_t)MT_STATE_WORDS * sizeof(uint32_t); }
 
-extern "C" int optex_legacy_normals(void* states, int n_streams, long count, double* out, long out_stride, void* stream) {
+static size_t normals_pairs(long count) { return (size_t)(count + 1) / 2 + 1; }
+
+extern "C" size_t optex_legacy_normals_ws_bytes(int n_streams, long count) {
+    if (n_streams <= 0 || count <= 0) return 0;
+    return align_up((size_t)n_streams * sizeof(NormalsMeta), 256) + (size_t)n_streams * normals_pairs(count) * 3 * sizeof(double);
+}
+
+extern "C" int optex_legacy_normals(void* states, int n_streams, long count, double* out, long out_stride, void* ws, size_t ws_bytes,
+                                    void* stream) {
     if (!states || !out || n_streams <= 0 || count < 0 || out_stride < count) {
         set_error("optex_legacy_normals: bad argument (n_streams=%d count=%ld out_stride=%ld)", n_streams, count, out_stride);
         return OPTEX_E_ARG;
     }
     if (count == 0) return OPTEX_OK;
+    if (int rc = check_ws("optex_legacy_normals", ws, ws_bytes, optex_legacy_normals_ws_bytes(n_streams, count))) return rc;
     hipStream_t st = as_stream(stream);
+    NormalsMeta* meta = static_cast<NormalsMeta*>(ws);
+    double* pairs = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up((size_t)n_streams * sizeof(NormalsMeta), 256));
+    const long pstride = (long)normals_pairs(count) * 3;
     ProfScope prof(KC_NORMALS, st, 0.0, 8.0 * (double)count * n_streams);
-    hipLaunchKernelGGL(legacy_normals_kernel, dim3(n_streams), dim3(256), 0, st, static_cast<uint32_t*>(states), count, out,
-                       out_stride);
-    return check_launch("legacy_normals_kernel");
+    hipLaunchKernelGGL(mt_accept_kernel, dim3(n_streams), dim3(64), 0, st, static_cast<uint32_t*>(states), count, pairs, pstride, meta);
+    int rc = check_launch("mt_accept_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(normals_emit_kernel, dim3((unsigned)((normals_pairs(count) + 255) / 256), n_streams), dim3(256), 0, st,
+                       static_cast<uint32_t*>(states), count, pairs, pstride, meta, out, out_stride);
+    return check_launch("normals_emit_kernel");
 }
 
 extern "C" long optex_rotation_normals(int N) { return (long)N * (N + 1) / 2 - 1; }

@@ -110,8 +110,9 @@ class DeviceNormals:
         run = self.stream if self.stream is not None else cur
         with torch.cuda.stream(run):
             out = torch.empty((self.n, int(total)), dtype=torch.float64, device=self.device)
+            ws = _lib.workspace(lib.optex_legacy_normals_ws_bytes(self.n, int(total)), self.device)
             _lib.check(lib.optex_legacy_normals(_lib.ptr(self.states), self.n, int(total), _lib.ptr(out), int(total),
-                                                ctypes_stream(run)))
+                                                _lib.ptr(ws), ws.numel(), ctypes_stream(run)))
             ev = None
             if self.stream is not None:
                 ev = torch.cuda.Event()

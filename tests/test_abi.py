@@ -58,10 +58,12 @@ def test_round4_entry_points_check_their_arguments_without_launching():
     assert lib.optex_mt19937_state_bytes() == (624 + 4) * 4
     buf = (ctypes.c_uint32 * 628)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.optex_legacy_normals(None, 1, 10, p, 10, None) == -1 and b"optex_legacy_normals" in lib.optex_last_error()
-    assert lib.optex_legacy_normals(p, 1, 10, p, 5, None) == -1      # out_stride smaller than count
-    assert lib.optex_legacy_normals(p, 0, 10, p, 10, None) == -1
-    assert lib.optex_legacy_normals(p, 1, 0, p, 0, None) == 0        # nothing to draw: no launch
+    assert lib.optex_legacy_normals(None, 1, 10, p, 10, p, 1 << 20, None) == -1 and b"optex_legacy_normals" in lib.optex_last_error()
+    assert lib.optex_legacy_normals(p, 1, 10, p, 5, p, 1 << 20, None) == -1      # out_stride smaller than count
+    assert lib.optex_legacy_normals(p, 0, 10, p, 10, p, 1 << 20, None) == -1
+    assert lib.optex_legacy_normals(p, 1, 0, p, 0, None, 0, None) == 0           # nothing to draw: no launch
+    need = lib.optex_legacy_normals_ws_bytes(2, 1001)
+    assert need >= 2 * 501 * 24 and lib.optex_legacy_normals(p, 2, 1001, p, 1001, p, need - 1, None) == -1   # undersized scratch
     assert lib.optex_mt19937_seed(None, 1, 5, 1, None) == -1 and lib.optex_mt19937_seed(p, 0, 5, 1, None) == -1
 
 
