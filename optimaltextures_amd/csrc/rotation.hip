@@ -198,7 +198,7 @@ struct NormalsMeta { long npairs; long lead; double cached; long pad; };   // pe
 __global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ states, long count, double* __restrict__ pairs,
                                                        long pairs_stride, NormalsMeta* __restrict__ meta) {
     __shared__ uint32_t key[2][MT_N];   // the block, ping-pong
-    __shared__ uint32_t sw[MT_N + 4];   // tempered words still to be consumed: <= 3 carried over + the rest of the block
+    __shared__ __attribute__((aligned(16))) uint32_t sw[MT_N + 4];   // tempered words still to be consumed: <= 3 carried over + the rest of the block
     __shared__ int s_stop;
     const int lane = threadIdx.x;
     uint32_t* st = states + (size_t)blockIdx.x * MT_STATE_WORDS;
@@ -221,23 +221,64 @@ __global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ st
     }
     __syncthreads();
     constexpr int W = MT_N - MT_M;  // 227: the recurrence is W wide
+    // This lone wavefront shares its SIMD with whatever the other streams run (the MFMA waves of a rotation GEMM, usually):
+    // it asks for issue priority — it needs few slots, and the sooner it is done the sooner the CU is the GEMM's alone — and
+    // every phase below is unrolled so that all of a phase's LDS reads are in flight together (one LDS latency per phase).
+    __builtin_amdgcn_s_setprio(3);
     while (done < want) {
         if (pos >= MT_N) {
             // next block, out of place: key[cur] -> key[cur ^ 1], three phases of up to 227 independent words
             const uint32_t* a = key[cur];
             uint32_t* b = key[cur ^ 1];
-            for (int k = lane; k < W; k += 64) b[k] = mt_twist(a[k], a[k + 1], a[k + MT_M]);
+            {
+                uint32_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = lane + 64 * i;
+                    v[i] = k < W ? mt_twist(a[k], a[k + 1], a[k + MT_M]) : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (lane + 64 * i < W) b[lane + 64 * i] = v[i];
+            }
             __syncthreads();
-            for (int k = lane; k < W; k += 64) b[k + W] = mt_twist(a[k + W], a[k + W + 1], b[k]);
+            {
+                uint32_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = lane + 64 * i;
+                    v[i] = k < W ? mt_twist(a[k + W], a[k + W + 1], b[k]) : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (lane + 64 * i < W) b[lane + 64 * i + W] = v[i];
+            }
             __syncthreads();
-            for (int k = 2 * W + lane; k < MT_N; k += 64) b[k] = mt_twist(a[k], k + 1 < MT_N ? a[k + 1] : b[0], b[k - W]);
+            {
+                uint32_t v[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int k = 2 * W + lane + 64 * i;
+                    v[i] = k < MT_N ? mt_twist(a[k], k + 1 < MT_N ? a[k + 1] : b[0], b[k - W]) : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    if (2 * W + lane + 64 * i < MT_N) b[2 * W + lane + 64 * i] = v[i];
+            }
             __syncthreads();
             cur ^= 1;
             pos = 0;
         }
         // the rest of the block, tempered, behind the words carried over from the last one
         const int avail = MT_N - pos, total = carry + avail, nat = total >> 2;
-        for (int i = lane; i < avail; i += 64) sw[carry + i] = mt_temper(key[cur][pos + i]);
+        {
+            uint32_t v[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) v[i] = lane + 64 * i < avail ? key[cur][pos + lane + 64 * i] : 0u;
+#pragma unroll
+            for (int i = 0; i < 10; i++)
+                if (lane + 64 * i < avail) sw[carry + lane + 64 * i] = mt_temper(v[i]);
+        }
         __syncthreads();
         bool stopped = false;
         for (int j0 = 0; j0 < nat && !stopped; j0 += 64) {   // 64 attempts at a time, in order
@@ -245,8 +286,9 @@ __global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ st
             bool acc = false;
             double x1 = 0.0, x2 = 0.0, r2 = 0.0;
             if (j < nat) {
-                x1 = 2.0 * mt_unit(sw[4 * j], sw[4 * j + 1]) - 1.0;
-                x2 = 2.0 * mt_unit(sw[4 * j + 2], sw[4 * j + 3]) - 1.0;
+                const uint4 wq = *reinterpret_cast<const uint4*>(sw + 4 * j);   // the attempt's four words
+                x1 = 2.0 * mt_unit(wq.x, wq.y) - 1.0;
+                x2 = 2.0 * mt_unit(wq.z, wq.w) - 1.0;
                 r2 = x1 * x1 + x2 * x2;
                 acc = !(r2 >= 1.0 || r2 == 0.0);
             }

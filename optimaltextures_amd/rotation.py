@@ -75,7 +75,8 @@ class DeviceNormals:
         words = lib.optex_mt19937_state_bytes() // 4
         self.device = torch.device(device)
         self.n = len(rngs)
-        self.stream = torch.cuda.Stream(self.device) if side_stream else None
+        # (a high-priority stream: the generator's lone wavefront per stream should not queue behind the main stream's launches)
+        self.stream = torch.cuda.Stream(self.device, priority=-1) if side_stream else None
         self._queue = deque()   # prefetched draws in stream order: (N, count, normals, event)
         run = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         ints = all(isinstance(r, (int, np.integer)) and 0 <= int(r) < 2 ** 32 for r in rngs)
