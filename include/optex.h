@@ -163,7 +163,7 @@ size_t optex_rotation_ws_bytes(int N, int count);
  * cache, what scipy's rvs draws from (optex.py:149) — advanced from / to a state of optex_mt19937_state_bytes() bytes per
  * stream: uint32 key[624], uint32 pos, uint32 has_gauss, double cached_gaussian = RandomState.get_state()[1:5].  `states`
  * holds n_streams of them back to back and is updated in place; stream s writes its next `count` values to
- * out + s * out_stride (out_stride >= count).  One wavefront per stream walks the words, all CUs do the arithmetic.  Words, accept / reject decisions and state are
+ * out + s * out_stride (out_stride >= count).  One workgroup per stream walks the words, all CUs do the arithmetic.  Words, accept / reject decisions and state are
  * exact; every floating-point operation is the host's IEEE operation except log(), which is correctly rounded here and
  * 0.52-ulp accurate in glibc: >= 99.8 % of the values equal numpy's bit for bit, the rest differ by a few ulp. */
 size_t optex_mt19937_state_bytes(void);

@@ -87,10 +87,10 @@ __global__ __launch_bounds__(64) void householder_apply_kernel(const double* __r
 // Sequential as written, parallel in fact: an ATTEMPT always consumes exactly four 32-bit words whether it is accepted or
 // not, so attempt j of a stretch of the stream is a pure function of words 4j .. 4j + 3, and the outputs are the accepted
 // attempts in order (a prefix sum of the accept flags).  The MT19937 recurrence x[k + 624] = x[k + 397] ^ t(x[k], x[k + 1])
-// is itself parallel 227 wide.  Two stages: one WAVEFRONT per stream regenerates the 624-word blocks (three 227-wide phases, out
+// is itself parallel 227 wide.  Two stages: one workgroup per stream regenerates the 624-word blocks (three 227-wide phases, out
 // of place: no read-before-write hazards), tempers them, takes the accept / reject decisions of a block's <= 157 attempts
-// 64 at a time and writes the accepted (x1, x2, r2) behind each other; then one thread per accepted pair, on all CUs, does
-// the expensive part (the logarithm).  State in / out: 624 key words, the position inside the
+// and writes the accepted (x1, x2, r2) behind each other; then one thread per accepted pair, on all CUs, does the
+// expensive part (the logarithm).  State in / out: 624 key words, the position inside the
 // block, the cache flag and the cached value — numpy's RandomState.get_state() tuple, so a stream can be handed over
 // from / to the host at any point.  Every operation is IEEE (no contraction, correctly rounded division and square root)
 // and identical to the host's, except log(): log_unit_interval below is correctly rounded, glibc's log is accurate to
@@ -188,22 +188,24 @@ __device__ __forceinline__ double mt_unit(uint32_t w0, uint32_t w1) {
     return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);   // (a power of two: exact)
 }
 
-// Stage 1, ONE WAVEFRONT per stream (the only sequential part): the MT19937 words and the accept / reject decisions.
-// Accepted attempts leave (x1, x2, r2) behind each other in `pairs`; the stream stops exactly behind the attempt that
-// completes the draw, so the state handed back is numpy's.  A single wavefront needs no workgroup barrier (the
-// __syncthreads() of a 64-thread block only orders its own LDS traffic) and shares its CU with whatever else runs there
-// at the cost of one wave slot: a whole bench step's 1.7 M normals take ~3 ms of one SIMD, beside the convolutions.
+// Stage 1, one workgroup of four wavefronts per stream (the only sequential part): the MT19937 words and the accept /
+// reject decisions.  Accepted attempts leave (x1, x2, r2) behind each other in `pairs`; the stream stops exactly behind
+// the attempt that completes the draw, so the state handed back is numpy's.  Per 624-word block: three 227-wide phases of
+// the recurrence (out of place), the tempering, one attempt per thread, a ballot prefix across the four waves — five
+// barriers, ~0.5 us.  (One wavefront alone, barrier-free, was tried: 2.2 us per block — a lone wave cannot issue its ~450
+// dependent instructions per block any faster.)
 struct NormalsMeta { long npairs; long lead; double cached; long pad; };   // per stream: pairs written, 1 if out[0] is the old cache
 
-__global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ states, long count, double* __restrict__ pairs,
-                                                       long pairs_stride, NormalsMeta* __restrict__ meta) {
+__global__ __launch_bounds__(256) void mt_accept_kernel(uint32_t* __restrict__ states, long count, double* __restrict__ pairs,
+                                                        long pairs_stride, NormalsMeta* __restrict__ meta) {
     __shared__ uint32_t key[2][MT_N];   // the block, ping-pong
     __shared__ __attribute__((aligned(16))) uint32_t sw[MT_N + 4];   // tempered words still to be consumed: <= 3 carried over + the rest of the block
+    __shared__ uint32_t wtot[4];
     __shared__ int s_stop;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* st = states + (size_t)blockIdx.x * MT_STATE_WORDS;
     double* pr = pairs + (size_t)blockIdx.x * pairs_stride;
-    for (int i = lane; i < MT_N; i += 64) key[0][i] = st[i];
+    for (int i = tid; i < MT_N; i += 256) key[0][i] = st[i];
     // uniform bookkeeping: block in use, position inside it, words carried over, pairs delivered
     int cur = 0, pos = (int)st[MT_N], carry = 0;
     const int had = (int)st[MT_N + 1];
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ st
     const long need = count - lead;                          // values to come from new pairs
     const long want = (need + 1) / 2;                        // pairs
     long done = 0;
-    if (lane == 0) {
+    if (tid == 0) {
         NormalsMeta m;
         m.npairs = want;
         m.lead = lead;
@@ -221,104 +223,69 @@ __global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ st
     }
     __syncthreads();
     constexpr int W = MT_N - MT_M;  // 227: the recurrence is W wide
-    // This lone wavefront shares its SIMD with whatever the other streams run (the MFMA waves of a rotation GEMM, usually):
-    // it asks for issue priority — it needs few slots, and the sooner it is done the sooner the CU is the GEMM's alone — and
-    // every phase below is unrolled so that all of a phase's LDS reads are in flight together (one LDS latency per phase).
-    __builtin_amdgcn_s_setprio(3);
     while (done < want) {
         if (pos >= MT_N) {
             // next block, out of place: key[cur] -> key[cur ^ 1], three phases of up to 227 independent words
             const uint32_t* a = key[cur];
             uint32_t* b = key[cur ^ 1];
-            {
-                uint32_t v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int k = lane + 64 * i;
-                    v[i] = k < W ? mt_twist(a[k], a[k + 1], a[k + MT_M]) : 0u;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (lane + 64 * i < W) b[lane + 64 * i] = v[i];
-            }
+            if (tid < W) b[tid] = mt_twist(a[tid], a[tid + 1], a[tid + MT_M]);
             __syncthreads();
-            {
-                uint32_t v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int k = lane + 64 * i;
-                    v[i] = k < W ? mt_twist(a[k + W], a[k + W + 1], b[k]) : 0u;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (lane + 64 * i < W) b[lane + 64 * i + W] = v[i];
-            }
+            if (tid < W) b[tid + W] = mt_twist(a[tid + W], a[tid + W + 1], b[tid]);
             __syncthreads();
-            {
-                uint32_t v[3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const int k = 2 * W + lane + 64 * i;
-                    v[i] = k < MT_N ? mt_twist(a[k], k + 1 < MT_N ? a[k + 1] : b[0], b[k - W]) : 0u;
-                }
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-                    if (2 * W + lane + 64 * i < MT_N) b[2 * W + lane + 64 * i] = v[i];
+            if (tid < MT_N - 2 * W) {
+                const int k = tid + 2 * W;
+                b[k] = mt_twist(a[k], k + 1 < MT_N ? a[k + 1] : b[0], b[k - W]);
             }
             __syncthreads();
             cur ^= 1;
             pos = 0;
         }
         // the rest of the block, tempered, behind the words carried over from the last one
-        const int avail = MT_N - pos, total = carry + avail, nat = total >> 2;
+        const int avail = MT_N - pos, total = carry + avail, nat = total >> 2;   // nat <= 157 attempts: one per thread
         {
-            uint32_t v[10];
+            uint32_t v[3];
 #pragma unroll
-            for (int i = 0; i < 10; i++) v[i] = lane + 64 * i < avail ? key[cur][pos + lane + 64 * i] : 0u;
+            for (int i = 0; i < 3; i++) v[i] = tid + 256 * i < avail ? key[cur][pos + tid + 256 * i] : 0u;
 #pragma unroll
-            for (int i = 0; i < 10; i++)
-                if (lane + 64 * i < avail) sw[carry + lane + 64 * i] = mt_temper(v[i]);
+            for (int i = 0; i < 3; i++)
+                if (tid + 256 * i < avail) sw[carry + tid + 256 * i] = mt_temper(v[i]);
         }
         __syncthreads();
-        bool stopped = false;
-        for (int j0 = 0; j0 < nat && !stopped; j0 += 64) {   // 64 attempts at a time, in order
-            const int j = j0 + lane;
-            bool acc = false;
-            double x1 = 0.0, x2 = 0.0, r2 = 0.0;
-            if (j < nat) {
-                const uint4 wq = *reinterpret_cast<const uint4*>(sw + 4 * j);   // the attempt's four words
-                x1 = 2.0 * mt_unit(wq.x, wq.y) - 1.0;
-                x2 = 2.0 * mt_unit(wq.z, wq.w) - 1.0;
-                r2 = x1 * x1 + x2 * x2;
-                acc = !(r2 >= 1.0 || r2 == 0.0);
-            }
-            const unsigned long long bal = __ballot(acc);
-            const long before = (long)__popcll(bal & ((1ull << lane) - 1ull));   // accepted attempts in front of mine
-            const long accepted = (long)__popcll(bal), room = want - done;
-            if (acc && before < room) {
-                double* p = pr + 3 * (done + before);
-                p[0] = x1;
-                p[1] = x2;
-                p[2] = r2;
-            }
-            if (accepted >= room) {
-                // the stream stops behind the attempt that delivers pair number want - 1: the words after it stay unconsumed
-                if (acc && before == room - 1) s_stop = j;
-                __syncthreads();
-                pos += 4 * (s_stop + 1) - carry;   // words of THIS block consumed from pos on (the carried ones were the last block's)
-                carry = 0;
-                done = want;
-                stopped = true;
-            } else {
-                done += accepted;
-            }
+        bool acc = false;
+        double x1 = 0.0, x2 = 0.0, r2 = 0.0;
+        if (tid < nat) {
+            const uint4 wq = *reinterpret_cast<const uint4*>(sw + 4 * tid);   // the attempt's four words
+            x1 = 2.0 * mt_unit(wq.x, wq.y) - 1.0;
+            x2 = 2.0 * mt_unit(wq.z, wq.w) - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+            acc = !(r2 >= 1.0 || r2 == 0.0);
         }
-        if (!stopped) {
+        const unsigned long long bal = __ballot(acc);
+        if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        long before = (long)__popcll(bal & ((1ull << lane) - 1ull));   // accepted attempts in front of mine
+        for (int k = 0; k < wave; k++) before += wtot[k];
+        const long accepted = (long)wtot[0] + wtot[1] + wtot[2] + wtot[3], room = want - done;
+        if (acc && before < room) {
+            double* p = pr + 3 * (done + before);
+            p[0] = x1;
+            p[1] = x2;
+            p[2] = r2;
+        }
+        if (accepted >= room) {
+            // the stream stops behind the attempt that delivers pair number want - 1: the words after it stay unconsumed
+            if (acc && before == room - 1) s_stop = tid;
+            __syncthreads();
+            pos += 4 * (s_stop + 1) - carry;   // words of THIS block consumed from pos on (the carried ones were the last block's)
+            carry = 0;
+            done = want;
+        } else {
+            done += accepted;
             const int left = total - 4 * nat;  // up to three words are left over: they open the next round
             uint32_t keep = 0u;
-            if (lane < left) keep = sw[4 * nat + lane];
+            if (tid < left) keep = sw[4 * nat + tid];
             __syncthreads();
-            if (lane < left) sw[lane] = keep;
+            if (tid < left) sw[tid] = keep;
             carry = left;
             pos = MT_N;
         }
@@ -326,8 +293,8 @@ __global__ __launch_bounds__(64) void mt_accept_kernel(uint32_t* __restrict__ st
     }
     // hand the state back (the loop leaves through its stop branch: nothing is carried over here).  An odd number of new
     // values leaves the second value of the last pair in the cache: stage 2 knows it and stores it (state word 626).
-    for (int i = lane; i < MT_N; i += 64) st[i] = key[cur][i];
-    if (lane == 0) {
+    for (int i = tid; i < MT_N; i += 256) st[i] = key[cur][i];
+    if (tid == 0) {
         st[MT_N] = (uint32_t)pos;
         if (count > 0) {
             st[MT_N + 1] = (uint32_t)(need & 1);
@@ -412,7 +379,7 @@ extern "C" int optex_legacy_normals(void* states, int n_streams, long count, dou
     double* pairs = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up((size_t)n_streams * sizeof(NormalsMeta), 256));
     const long pstride = (long)normals_pairs(count) * 3;
     ProfScope prof(KC_NORMALS, st, 0.0, 8.0 * (double)count * n_streams);
-    hipLaunchKernelGGL(mt_accept_kernel, dim3(n_streams), dim3(64), 0, st, static_cast<uint32_t*>(states), count, pairs, pstride, meta);
+    hipLaunchKernelGGL(mt_accept_kernel, dim3(n_streams), dim3(256), 0, st, static_cast<uint32_t*>(states), count, pairs, pstride, meta);
     int rc = check_launch("mt_accept_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(normals_emit_kernel, dim3((unsigned)((normals_pairs(count) + 255) / 256), n_streams), dim3(256), 0, st,

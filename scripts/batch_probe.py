@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where does a SMALL batch lose throughput?  bench.py's step at B textures per step (BASELINE config 4 shards 8 per GPU),
-three ways: as the bench runs it (rotations drawn from the numpy stream inside the step), with the rotations of every
-(pass, layer) cached on the device beforehand (no host RNG, no host->device copy inside the step: the GPU-side bound), and
-the host cost of drawing one step's normals alone.
+four ways: rotations drawn from the numpy stream on the HOST inside the step (bench.py --host_rng), the same stream advanced
+on the DEVICE (bench.py's default, rotation.DeviceNormals), the rotations of every (pass, layer) cached on the device
+beforehand (no RNG at all inside the step: the GPU-side bound), and the host cost of drawing one step's normals alone.
     python scripts/batch_probe.py [B ...]"""
 import os
 import sys
@@ -39,6 +39,19 @@ def main():
             host = time.perf_counter() - t0
             torch.cuda.synchronize()
             live = time.perf_counter() - t0
+
+            def run_dev(n):
+                for q in range(n):
+                    tex.rng = otdist.rotation_stream(0, q, dev)
+                    tex.forward(otdist.texture_noise(q * B, B, (3, 512, 512), dev), [style])
+
+            run_dev(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_dev(steps)
+            host_d = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            devt = time.perf_counter() - t0
             # the same steps with every rotation batch of the call served from a device-side cache
             cache, own = {}, rotation.rotations
 
@@ -65,7 +78,8 @@ def main():
         for it in (13, 12, 10, 9, 8):
             r.normal(size=(it, 256 * 257 // 2 - 1))
         draw = time.perf_counter() - t0
-        print(f"B = {B:3d}: live {B * steps / live:7.1f} textures/s ({1e3 * live / steps:6.1f} ms/step, host enqueue {1e3 * host / steps:6.1f} ms) | "
+        print(f"B = {B:3d}: host stream {B * steps / live:7.1f} textures/s ({1e3 * live / steps:6.1f} ms/step, host enqueue {1e3 * host / steps:6.1f} ms) | "
+              f"device stream {B * steps / devt:7.1f} textures/s ({1e3 * devt / steps:6.1f} ms/step, host enqueue {1e3 * host_d / steps:6.1f} ms) | "
               f"cached rotations {B * steps / gpu:7.1f} textures/s ({1e3 * gpu / steps:6.1f} ms/step, host enqueue {1e3 * host_c / steps:6.1f} ms) | "
               f"drawing one step's 1.71 M normals on the host: {1e3 * draw:.1f} ms")
 
