@@ -45,9 +45,9 @@ def synthetic_style(device, seed=0):
     return (img + 0.05 * torch.randn(1, 3, 736, 512, generator=g)).clamp(0, 1).to(device)
 
 
-def make_texturizer(hist_mode, device, fuse_rotations=False, no_pca=True, independent=True):
+def make_texturizer(hist_mode, device, fuse_rotations=False, no_pca=True, independent=True, fold_pca=False):
     return OptimalTexture(size=SIZE, iters=ITERS, passes=PASSES, hist_mode=hist_mode, no_pca=no_pca, layers=(LAYER,),
-                          independent=independent, fuse_rotations=fuse_rotations).to(device).eval()
+                          independent=independent, fuse_rotations=fuse_rotations, fold_pca=fold_pca).to(device).eval()
 
 
 def pmc_traffic():
@@ -432,8 +432,21 @@ def main():
                     step(m)
                     torch.cuda.synchronize()
                     pcad[mode] = round(B / (time.perf_counter() - t0), 3)
+            # labelled re-association: the projection inside the first rotation, the unprojection inside the last
+            pcaf = {}
+            with torch.inference_mode():
+                for mode in ("chol", "cdf"):
+                    m = make_texturizer(mode, device, no_pca=False, fold_pca=True)
+                    step(m)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    step(m)
+                    torch.cuda.synchronize()
+                    pcaf[mode] = round(B / (time.perf_counter() - t0), 3)
             result["textures_per_s_pca_default"] = {
-                "by_hist_mode": pcad, "config": f"PCA on (the reference's default), {B} independent textures per step, otherwise the headline configuration"}
+                "by_hist_mode": pcad, "folded_projection_by_hist_mode": pcaf,
+                "config": f"PCA on (the reference's default), {B} independent textures per step, otherwise the headline configuration; "
+                          "folded = project / unproject inside the first / last rotation (optex_ot_loop_pca), a labelled re-association"}
         if "ownrotations" in args.other_modes.split(","):
             # un-shared rotations: every texture draws its own sequence from its own numpy stream (the reference run as B
             # separate B = 1 jobs, optex.py:149,168) — nothing on the style side is shared either, and the host draws

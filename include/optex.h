@@ -210,6 +210,20 @@ int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, lon
                   const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content, float strength,
                   int fuse_rotations, void* ws, size_t ws_bytes, void* stream);
 
+/* The same loop between the PCA projection and unprojection of optex.py:109-110,119-120 (ABI 7), the reference's
+ * default (PCA on):   x = feat @ E;  [iterations];  feat = x @ E^T   with E = eigvecs [C_full, C].
+ * x_full [n_seg, C_full, n] holds the un-projected encoder features on entry and the un-projected result on exit; style
+ * [src_n_seg, C, ns] and content (NULL or [n_seg, C, n]) are projected already (they are per call, not per iteration); eig is
+ * E row-major [C_full, C], eig_t its transpose [C, C_full]; R32 / Rt32 [iters, C, C], one sequence for the batch.
+ * The projection is FOLDED into the first rotation,  (feat @ E) @ R_0 = feat @ (E R_0), and — cdf / sort without a content
+ * blend — the unprojection into the last rotation back,  (m @ R_l^T) @ E^T = m @ (E R_l)^T: two of the 2 * iters + 2
+ * feature-map GEMMs of a (pass, layer) disappear.  Same products in another association: results agree with
+ * project -> optex_ot_loop -> unproject to fp32 round-off (tests/test_gpu_parity.py), not bit for bit.  fuse_rotations = 0. */
+size_t optex_ot_loop_pca_ws_bytes(int mode, long n, long ns, int C, int C_full, int n_seg, int src_n_seg, int iters);
+int optex_ot_loop_pca(int mode, float* x_full, int C_full, const float* eig, const float* eig_t, long n, int n_seg,
+                      const float* style, long ns, int src_n_seg, int C, const float* R32, const float* Rt32, int iters,
+                      const float* content, float strength, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * N3  element-wise glue between the VGG convolutions, vgg.py:14-135: conv bias add, nn.ReLU,
  * nn.MaxPool2d(2, 2, ceil_mode=True) (vgg.py:26 ...), nn.UpsamplingNearest2d(2) (vgg.py:82 ...) and the

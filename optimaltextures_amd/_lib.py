@@ -47,6 +47,8 @@ SIGNATURES = {
     "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "optex_ot_loop_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I, _L]),
     "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _L, _I, _P, _F, _I, _P, _SZ, _P]),
+    "optex_ot_loop_pca_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I]),
+    "optex_ot_loop_pca": (_I, [_I, _P, _I, _P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _I, _P, _F, _P, _SZ, _P]),
     "optex_vgg_glue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "optex_vgg_glue_layout": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "optex_prof_enable": (_I, [_I]),

@@ -177,16 +177,30 @@ int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, 
 }
 
 
+// The PCA projection folded into the first rotation and the unprojection into the last (optex.py:110,120):
+//   (feat @ E) @ R_0 == feat @ (E R_0),   (m @ R_l^T) @ E^T == m @ (E R_l)^T
+// — iteration 0 reads the un-projected features with the C_full x C matrix E R_0, the last iteration writes un-projected
+// features with (E R_l)^T: two feature-map GEMMs of a (pass, layer) disappear.  Same products, another association.
+struct Fold {
+    const float* xin = nullptr;   // [n_seg, Cf, n] un-projected input of iteration 0
+    const float* ER0 = nullptr;   // [Cf, C] = E R_0
+    int Cf = 0;
+    float* xout = nullptr;        // [n_seg, Cf, n] un-projected output of the last iteration, or NULL: the loop ends in k-space
+    const float* G = nullptr;     // [C, Cf] = (E R_last)^T
+};
+
 // optex.py:170  rotated = feature @ rotation  on the loop's layouts, with the per-row statistics of the result taken in the
-// GEMM's epilogue when the launch takes the hot-loop kernel (rowstat 1 = min / max, 2 = sums; *took says whether it did)
+// GEMM's epilogue when the launch takes the hot-loop kernel (rowstat 1 = min / max, 2 = sums; *took says whether it did).
+// K: channels of the input map (0 = C; the folded projection reads C_full channels)
 int rotate_with_stats(const float* R, long r_ss, const float* x, float* y, int C, long n, int n_seg, int rowstat, float* rs_a,
-                      float* rs_b, bool* took, hipStream_t st, long ldy = 0) {
+                      float* rs_b, bool* took, hipStream_t st, long ldy = 0, int K = 0) {
     if (ldy == 0) ldy = n;
+    if (K == 0) K = C;
     GemmArgs a;
     a.At = R; a.lda = C; a.at_ss = r_ss;
-    a.B = x; a.ldb = n; a.b_ss = (long)C * n;
+    a.B = x; a.ldb = n; a.b_ss = (long)K * n;
     a.O = y; a.ldo = ldy; a.o_ss = (long)C * ldy;
-    a.M = C; a.K = C; a.n = n; a.n_seg = n_seg;
+    a.M = C; a.K = K; a.n = n; a.n_seg = n_seg;
     a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
     a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.sym = 0; a.prof_cls = KC_GEMM;
     a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
@@ -268,7 +282,8 @@ int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int 
 
 // G: rotation sets per iteration (prepare_style); r_ss: elements between the rotation sets of two segments (0 = shared)
 int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int Ss, int G, int C, const float* R32,
-                const float* Rt32, long r_ss, int iters, const float* content, float strength, int fused, LoopWs& w, void* stream) {
+                const float* Rt32, long r_ss, int iters, const float* content, float strength, int fused, LoopWs& w, void* stream,
+                const Fold* fold = nullptr) {
     hipStream_t st = as_stream(stream);
     const size_t cc = (size_t)C * C;
     const long xs = (long)C * n;
@@ -322,7 +337,11 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
             // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (+ the row sums for the means, in the epilogue)
             bool sums = false;
             const long ldy = padded_ld(n);
-            if ((rc = rotate_with_stats(R, r_ss, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st, ldy))) return rc;
+            if (fold && it == 0)   // the PCA projection rides in the first rotation: E R_0 on the un-projected map
+                rc = rotate_with_stats(fold->ER0, 0, fold->xin, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st, ldy, fold->Cf);
+            else
+                rc = rotate_with_stats(R, r_ss, x, w.y, C, n, n_seg, 2, w.rs_a, nullptr, &sums, st, ldy);
+            if (rc) return rc;
             // histmatch.py:16-18  mu_t, cov_t = hist_t hist_t^T / N + eps I   (statistics of the ROTATED map, like the reference)
             if ((rc = linear_stats_parts(w.y, ldy, (long)C * ldy, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws,
                                          w.stats_ws_bytes, sums ? w.rs_a : nullptr, w.rs_parts, stream)))
@@ -383,9 +402,9 @@ extern "C" size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n
     return b.off;
 }
 
-extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
-                             const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content,
-                             float strength, int fuse_rotations, void* ws, size_t ws_bytes, void* stream) {
+static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
+                        const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content,
+                        float strength, int fuse_rotations, void* ws, size_t ws_bytes, void* stream, const Fold* fold) {
     if (!x || !style || !R32 || !Rt32 || !ws || n <= 0 || ns <= 0 || C < 2 || n_seg <= 0 || iters < 0) {
         set_error("optex_ot_loop: bad argument (n=%ld ns=%ld C=%d n_seg=%d iters=%d)", n, ns, C, n_seg, iters);
         return OPTEX_E_ARG;
@@ -434,9 +453,13 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
     // segment per target segment (nothing on the style side is shared any more, optex.py:168-171 run per image).
     const int rs_seg = r_seg_stride != 0 ? n_seg : src_n_seg;
     w.layout(bump, mode, n, ns, C, n_seg, rs_seg, iters, fuse_rotations, r_seg_stride != 0);
+    if (fold && (fuse_rotations != 0 || r_seg_stride != 0)) {
+        set_error("optex_ot_loop: the folded PCA projection runs with fuse_rotations = 0 and one rotation sequence per batch");
+        return OPTEX_E_UNSUPPORTED;
+    }
     if (linear)
         return linear_loop(mode, x, n, n_seg, style, ns, src_n_seg, rs_seg, C, R32, Rt32, r_seg_stride, iters, content, strength,
-                           fuse_rotations, w, stream);
+                           fuse_rotations, w, stream, fold);
 
     hipStream_t st = as_stream(stream);
     const long xs = (long)C * n, ss = (long)C * ns;
@@ -501,7 +524,11 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
         // optex.py:170  rotated_pastiche = pastiche_feature @ rotation   (+ per-channel min / max in the epilogue: it saves the
         // cdf matcher histmatch.py:52-53's pass over the rotated map, and the sort matcher its in-kernel range reduction)
         bool mm = false;
-        if ((rc = rotate_with_stats(R, r_seg_stride, x, w.y, C, n, n_seg, 1, w.rs_a, w.rs_b, &mm, st))) return rc;
+        if (fold && it == 0)   // the PCA projection rides in the first rotation: E R_0 on the un-projected map
+            rc = rotate_with_stats(fold->ER0, 0, fold->xin, w.y, C, n, n_seg, 1, w.rs_a, w.rs_b, &mm, st, 0, fold->Cf);
+        else
+            rc = rotate_with_stats(R, r_seg_stride, x, w.y, C, n, n_seg, 1, w.rs_a, w.rs_b, &mm, st);
+        if (rc) return rc;
         // optex.py:171  rotated_style = style_feature @ rotation   (one copy per rotation set; hoisted: done above)
         const float* ys = w.hoist ? w.ys + (size_t)it * rs_seg * ss : w.ys;
         if (!w.hoist &&
@@ -519,9 +546,84 @@ extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float*
                                  mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, w.hoist ? ys : nullptr);
         if (rc) return rc;
         // optex.py:175 + 115-117  pastiche = matched @ rotation.T ; content blend
-        if ((rc = optex_gemm_tn(Rt, C, r_seg_stride, w.y, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
-                                nullptr, 0, nullptr, 0, content, strength, stream)))
-            return rc;
+        if (fold && fold->xout && it == iters - 1)   // ... and the PCA unprojection rides in the last one: (E R_l)^T
+            rc = optex_gemm_tn(fold->G, fold->Cf, 0, w.y, n, xs, OPTEX_CHANNEL_MAJOR, fold->xout, n, (long)fold->Cf * n,
+                               OPTEX_CHANNEL_MAJOR, fold->Cf, C, n, n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream);
+        else
+            rc = optex_gemm_tn(Rt, C, r_seg_stride, w.y, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
+                               nullptr, 0, nullptr, 0, content, strength, stream);
+        if (rc) return rc;
     }
     return OPTEX_OK;
+}
+
+extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
+                             const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content,
+                             float strength, int fuse_rotations, void* ws, size_t ws_bytes, void* stream) {
+    return ot_loop_impl(mode, x, n, n_seg, style, ns, src_n_seg, C, R32, Rt32, r_seg_stride, iters, content, strength,
+                        fuse_rotations, ws, ws_bytes, stream, nullptr);
+}
+
+// ---- the loop between the PCA projection and unprojection of optex.py:110,120 -----------------------------------------------
+static size_t pca_extra_bytes(long n, int C, int C_full, int n_seg) {
+    return align_up((size_t)n_seg * C * n * sizeof(float), 256) + 2 * align_up((size_t)C_full * C * sizeof(float), 256);
+}
+
+extern "C" size_t optex_ot_loop_pca_ws_bytes(int mode, long n, long ns, int C, int C_full, int n_seg, int src_n_seg, int iters) {
+    return align_up(optex_ot_loop_ws_bytes(mode, n, ns, C, n_seg, src_n_seg, iters, 0, 0), 256) + pca_extra_bytes(n, C, C_full, n_seg);
+}
+
+extern "C" int optex_ot_loop_pca(int mode, float* x_full, int C_full, const float* eig, const float* eig_t, long n, int n_seg,
+                                 const float* style, long ns, int src_n_seg, int C, const float* R32, const float* Rt32, int iters,
+                                 const float* content, float strength, void* ws, size_t ws_bytes, void* stream) {
+    if (!x_full || !eig || !eig_t || !style || !R32 || !Rt32 || !ws || n <= 0 || ns <= 0 || C < 2 || C_full < C || n_seg <= 0 ||
+        iters < 0) {
+        set_error("optex_ot_loop_pca: bad argument (n=%ld ns=%ld C=%d C_full=%d n_seg=%d iters=%d)", n, ns, C, C_full, n_seg, iters);
+        return OPTEX_E_ARG;
+    }
+    if (int rc = check_ws("optex_ot_loop_pca", ws, ws_bytes, optex_ot_loop_pca_ws_bytes(mode, n, ns, C, C_full, n_seg, src_n_seg, iters)))
+        return rc;
+    const size_t base = align_up(optex_ot_loop_ws_bytes(mode, n, ns, C, n_seg, src_n_seg, iters, 0, 0), 256);
+    char* p = static_cast<char*>(ws) + base;
+    float* xk = reinterpret_cast<float*>(p);                                  // the loop's state between iterations, k-space
+    p += align_up((size_t)n_seg * C * n * sizeof(float), 256);
+    float* ER0 = reinterpret_cast<float*>(p);
+    p += align_up((size_t)C_full * C * sizeof(float), 256);
+    float* G = reinterpret_cast<float*>(p);
+    const long xfs = (long)C_full * n, xs = (long)C * n;
+    int rc;
+    if (iters == 0) {
+        // optex.py:110 then :120 with nothing in between: x_full <- (x_full @ E) @ E^T, the projector onto the kept subspace
+        if ((rc = optex_gemm_tn(eig, C, 0, x_full, n, xfs, OPTEX_CHANNEL_MAJOR, xk, n, xs, OPTEX_CHANNEL_MAJOR, C, C_full, n, n_seg,
+                                nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+            return rc;
+        return optex_gemm_tn(eig_t, C_full, 0, xk, n, xs, OPTEX_CHANNEL_MAJOR, x_full, n, xfs, OPTEX_CHANNEL_MAJOR, C_full, C, n, n_seg,
+                             nullptr, 0, nullptr, 0, nullptr, 0.f, stream);
+    }
+    // E R_0 as the [C_full, C] matrix of the first rotation: (E R_0)[c][m] = sum_j E[c][j] R_0[j][m] — the transposing GEMM reads
+    // E as a "pixel-major" map of C_full pixels and stores the result pixel-major, i.e. row-major [C_full, C]
+    if ((rc = optex_gemm_tn(R32, C, 0, eig, C, 0, OPTEX_PIXEL_MAJOR, ER0, C, 0, OPTEX_PIXEL_MAJOR, C, C, C_full, 1, nullptr, 0, nullptr,
+                            0, nullptr, 0.f, stream)))
+        return rc;
+    Fold f;
+    f.xin = x_full;
+    f.ER0 = ER0;
+    f.Cf = C_full;
+    // the unprojection folds where the last step is a plain rotation back: cdf / sort without a content blend (the blend
+    // works on the un-rotated k-space map; the linear modes' last GEMM already carries the transfer operator and the means)
+    const bool fold_out = mode < MODE_CHOL && content == nullptr;
+    if (fold_out) {
+        // (E R_l)^T as the [C, C_full] matrix of the last rotation back: the same product stored channel-major
+        if ((rc = optex_gemm_tn(R32 + (size_t)(iters - 1) * C * C, C, 0, eig, C, 0, OPTEX_PIXEL_MAJOR, G, C_full, 0,
+                                OPTEX_CHANNEL_MAJOR, C, C, C_full, 1, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+            return rc;
+        f.xout = x_full;
+        f.G = G;
+    }
+    if ((rc = ot_loop_impl(mode, xk, n, n_seg, style, ns, src_n_seg, C, R32, Rt32, 0, iters, content, strength, 0, ws, base, stream, &f)))
+        return rc;
+    if (fold_out) return OPTEX_OK;
+    // optex.py:120  pastiche_feature @ eigvecs.T
+    return optex_gemm_tn(eig_t, C_full, 0, xk, n, xs, OPTEX_CHANNEL_MAJOR, x_full, n, xfs, OPTEX_CHANNEL_MAJOR, C_full, C, n, n_seg,
+                         nullptr, 0, nullptr, 0, nullptr, 0.f, stream);
 }

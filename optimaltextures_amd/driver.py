@@ -300,7 +300,7 @@ class OptimalTexture(torch.nn.Module):
                  mixing_alpha: float = 0.5, no_pca: bool = False, no_multires: bool = False,
                  layers=(5, 4, 3, 2, 1), models_dir: Optional[str] = None, independent: bool = False,
                  fuse_rotations: bool = False, allow_synthetic: bool = False, index_by_position: bool = False,
-                 codec_layout: Optional[str] = None, pca_fit: Optional[str] = None):
+                 codec_layout: Optional[str] = None, pca_fit: Optional[str] = None, fold_pca: bool = False):
         super().__init__()
         self.hist_mode = hist_mode
         self.color_transfer = color_transfer
@@ -310,6 +310,10 @@ class OptimalTexture(torch.nn.Module):
         self.use_pca = not no_pca
         self.pca_fit = None if pca_fit is None else _route(pca_fit)  # "gram" / "svd" (optex.py:183's literal call); None = PCA_FIT
         self.independent = independent
+        # optional re-association: PCA project / unproject folded into the first / last rotation of every
+        # (pass, layer) — (feat @ E) @ R_0 = feat @ (E R_0) — two feature-map GEMMs fewer; independent textures with one
+        # shared rotation sequence only; never the default (fp32 round-off differences)
+        self.fold_pca = fold_pca
         self.fuse_rotations = fuse_rotations  # optional re-association (m @ R^T) @ R' -> m @ (R^T R'), cdf / sort only
         self.passes = passes
         self.iters_per_pass_and_layer, self.sizes = get_iters_and_sizes(size, iters, passes, not no_multires)
@@ -515,14 +519,33 @@ class OptimalTexture(torch.nn.Module):
                 feat = encoder.features(pastiche)
                 b, c, h, w = feat.shape
                 x = feat.reshape(b, c, h * w)
+                blend = len(content_features) > 0 and enc_index <= 2
+                strength = self.content_strength / 2 ** (4 - enc_index) if blend else 0.0
+                n_it = layer_iters(self.iters_per_pass_and_layer, p, enc_index)
+                folded = (self.use_pca and self.fold_pca and self.independent and not self.fuse_rotations and n_it > 0 and
+                          not isinstance(self.rng, (list, tuple)) and not (isinstance(self.rng, rotation.DeviceNormals) and self.rng.n != 1)
+                          and self.hist_mode in LOOP_MODES and style_features[li].shape[1] <= ops.LINEAR_MAX_C)
+                if folded:
+                    # optex.py:110 + 112-117 + 120 in one call, projection and unprojection inside the rotations
+                    k = int(style_eigvs[li].shape[1])
+                    R32, Rt32 = (self.rng.rotations(k, n_it) if isinstance(self.rng, rotation.DeviceNormals)
+                                 else rotation.rotations(k, n_it, x.device, rng=self.rng))
+                    cf = content_features[li] if blend else None
+                    if cf is not None and cf.shape[0] != b:
+                        cf = cf.expand(b, k, h * w).contiguous()
+                    x = ops.ot_loop_pca(self.hist_mode, x.contiguous(), style_eigvs[li], style_eigvs[li].t().contiguous(),
+                                        style_features[li], R32, Rt32, content=cf, strength=strength)
+                    pastiche = decoder.decode(x.view(b, -1, h, w))
+                    if on_layer is not None:
+                        replaced = on_layer(p, li, pastiche)
+                        if replaced is not None:
+                            pastiche = replaced
+                    continue
                 if self.use_pca:
                     x = project_cm(x.contiguous(), style_eigvs[li])
                 elif not x.is_contiguous():
                     x = x.contiguous()
-                blend = len(content_features) > 0 and enc_index <= 2
-                strength = self.content_strength / 2 ** (4 - enc_index) if blend else 0.0
-                x = ot_iterations(x, style_features[li], self.hist_mode,
-                                  layer_iters(self.iters_per_pass_and_layer, p, enc_index),
+                x = ot_iterations(x, style_features[li], self.hist_mode, n_it,
                                   content=content_features[li] if blend else None, strength=strength,
                                   pooled=not self.independent, rng=self.rng, fuse_rotations=self.fuse_rotations)
                 if self.use_pca:

@@ -249,6 +249,26 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
     return x
 
 
+def ot_loop_pca(mode, x_full, eigvecs, eigvecs_t, style, R32, Rt32, content=None, strength=0.0):
+    """optex.py:110 -> 112-117 -> 120 in one C call: x_full [S, C_full, n] un-projected features, updated IN PLACE; eigvecs
+    [C_full, k] and its transpose; style [Ss, k, ns] and content (None or [S, k, n]) projected already; R32 / Rt32 [iters, k, k].
+    The projection rides in the first rotation and (cdf / sort, no content) the unprojection in the last (optex_ot_loop_pca)."""
+    lib = _lib.lib()
+    S, Cf, n = x_full.shape
+    Ss, C, ns = style.shape
+    iters = R32.shape[0]
+    assert eigvecs.shape == (Cf, C) and eigvecs_t.shape == (C, Cf) and eigvecs.is_contiguous() and eigvecs_t.is_contiguous()
+    assert x_full.is_contiguous() and style.is_contiguous() and R32.shape == (iters, C, C) and Rt32.shape == (iters, C, C)
+    if content is not None:
+        assert content.shape == (S, C, n) and content.is_contiguous()
+    m = LOOP_MODES[mode]
+    ws = workspace(lib.optex_ot_loop_pca_ws_bytes(m, n, ns, C, Cf, S, Ss, iters), x_full.device)
+    check(lib.optex_ot_loop_pca(m, ptr(_f32c(x_full)), Cf, ptr(_f32c(eigvecs)), ptr(_f32c(eigvecs_t)), n, S, ptr(_f32c(style)), ns, Ss,
+                                C, ptr(R32), ptr(Rt32), iters, ptr(content), ctypes.c_float(strength), ptr(ws), ws.numel(),
+                                stream_ptr()))
+    return x_full
+
+
 def vgg_glue(x, bias=None, relu=False, pool=False, up=False, pad=0, out_nhwc=False):
     """pad(up(pool(relu(x + bias)))) in one pass over a fp32 tensor of logical shape [N, C, H, W] (vgg.py's module glue,
     see include/optex.h).  x is either NCHW-contiguous or channels-last (a permuted view of [N, H, W, C] memory, what

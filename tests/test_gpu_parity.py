@@ -857,6 +857,91 @@ def test_ot_loop_is_hipgraph_capturable(dev, mode, C, blend):
         static_x.copy_(x0)
 
 
+# ================================================================================================ N1: PCA folded into the rotations
+@pytest.mark.parametrize("mode,blend,Cf,k,n,ns,iters", [("cdf", False, 64, 23, 1024, 768, 3), ("sort", False, 64, 23, 1024, 768, 2),
+                                                        ("cdf", True, 64, 23, 1024, 768, 3), ("cdf", False, 256, 181, 4096, 3072, 2),
+                                                        ("sort", False, 128, 84, 2048, 1536, 1)])
+def test_ot_loop_pca_folded_vs_oracle_bit_exact(dev, mode, blend, Cf, k, n, ns, iters):
+    """optex_ot_loop_pca (optex.py:110, 112-117, 120): the PCA projection folded into the first rotation,
+    (feat @ E) @ R_0 = feat @ (E R_0), and — without a content blend — the unprojection into the last one.  Bit-exact against
+    the oracle's restatement of exactly that association (every product a k-ordered fma chain), cdf and sort."""
+    from optimaltextures_amd import ops
+    S = 2
+    rng = np.random.default_rng(Cf + k + iters)
+    feat = relu_feat(rng, S, Cf, n, scale=2.0, shift=0.3)
+    E = np.linalg.qr(rng.standard_normal((Cf, k)))[0].astype(np.float32)      # an orthonormal basis like fit_pca's
+    sty = (rng.standard_normal((1, k, ns)) * 1.5).astype(np.float32)
+    content = (rng.standard_normal((S, k, n)) * 2).astype(np.float32) if blend else None
+    lr = orc.LegacyRNG(k)
+    R = np.stack([orc.random_rotation(k, lr) for _ in range(iters)]).astype(np.float32)
+    Rt = np.ascontiguousarray(R.transpose(0, 2, 1))
+    Et = np.ascontiguousarray(E.T)
+    xd = cu(feat, dev)
+    ops.ot_loop_pca(mode, xd, cu(E, dev), cu(Et, dev), cu(sty, dev), cu(R, dev), cu(Rt, dev),
+                    content=cu(content, dev) if blend else None, strength=0.05 if blend else 0.0)
+    got = xd.cpu().numpy()
+    match = orc.cdf_match if mode == "cdf" else orc.sort_match
+    ER0 = np.ascontiguousarray(orc.gemm_tn(R[0], Et).T)                         # [Cf, k] = E R_0
+    G = orc.gemm_tn(R[-1], Et)                                                  # [k, Cf] = (E R_l)^T
+    for s in range(S):
+        w = None
+        for it in range(iters):
+            rp = orc.gemm_tn(ER0, feat[s]) if it == 0 else orc.rotate_cm(w, R[it])
+            m = match(rp, orc.rotate_cm(sty[0], R[it]))
+            if it == iters - 1 and not blend:
+                out = orc.gemm_tn(G, m)                                         # the unprojection inside the last rotation back
+            else:
+                w = orc.unrotate_cm(m, R[it])
+                if blend:
+                    w = orc.content_blend(w, content[s], 0.05)
+        if blend:
+            out = orc.gemm_tn(Et, w)                                            # optex.py:120 on its own
+        assert biteq(got[s], out), f"{mode} segment {s}: {np.count_nonzero(got[s] != out)} of {out.size} elements differ"
+
+
+@pytest.mark.parametrize("mode", ["chol", "pca", "cdf"])
+def test_ot_loop_pca_folded_vs_unfolded(dev, mode):
+    """the folded call against project -> optex_ot_loop -> unproject on the device: the same map to fp32 round-off in the
+    smooth modes; in cdf mode (a discontinuous map) 99.5 % of the elements within 1e-4 of the range, the rest within a bin"""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.driver import project_cm, unproject_cm
+    S, Cf, k, n, ns, iters = 3, 256, 181, 4096, 3072, 3
+    rng = np.random.default_rng(len(mode))
+    feat = cu(relu_feat(rng, S, Cf, n, scale=2.0, shift=0.3), dev)
+    E = cu(np.linalg.qr(rng.standard_normal((Cf, k)))[0].astype(np.float32), dev)
+    Et = E.t().contiguous()
+    sty = cu((rng.standard_normal((1, k, ns)) * 1.5).astype(np.float32), dev)
+    lr = orc.LegacyRNG(5)
+    R = np.stack([orc.random_rotation(k, lr) for _ in range(iters)]).astype(np.float32)
+    Rd, Rtd = cu(R, dev), cu(np.ascontiguousarray(R.transpose(0, 2, 1)), dev)
+    folded = ops.ot_loop_pca(mode, feat.clone(), E, Et, sty, Rd, Rtd).cpu().numpy()
+    xk = project_cm(feat, E)
+    ops.ot_loop(mode, xk, sty, Rd, Rtd)
+    plain = unproject_cm(xk, Et).cpu().numpy()
+    err = np.abs(folded - plain)
+    scale = np.abs(plain).max()
+    if mode == "cdf":
+        assert np.mean(err <= 1e-4 * scale) >= 0.995 and err.max() <= 0.05 * scale, (np.mean(err <= 1e-4 * scale), err.max() / scale)
+    else:
+        assert err.max() <= 2e-4 * scale, err.max() / scale
+
+
+def test_forward_with_folded_pca_equals_unfolded(dev):
+    """OptimalTexture(fold_pca=True) against the default driver path on the same rotations (chol: a smooth map)"""
+    from optimaltextures_amd.driver import OptimalTexture
+    kw = dict(size=128, iters=60, passes=2, hist_mode="chol", layers=(3, 2), independent=True)
+    g = torch.Generator().manual_seed(1)
+    style = torch.rand(1, 3, 96, 128, generator=g).to(dev)
+    noise = torch.rand(2, 3, 128, 128, generator=g).to(dev)
+    outs = []
+    for fold in (False, True):
+        tex = OptimalTexture(fold_pca=fold, **kw).to(dev).eval()
+        tex.rng = np.random.RandomState(11)
+        with torch.inference_mode():
+            outs.append(tex.forward(noise.clone(), [style]).cpu().numpy())
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-3 * np.abs(outs[0]).max(), np.abs(outs[0] - outs[1]).max()
+
+
 # ================================================================================================ the numpy stream on the device
 def _ulps(a, b):
     return np.abs(a.view(np.int64) - b.view(np.int64))
