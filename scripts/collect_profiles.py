@@ -12,7 +12,10 @@ tag, pre = sys.argv[1], sys.argv[2]
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("bench_default.json", "bench_b64_cdf_kernel_summary.md", "bench_b64_sort_kernel_summary.md",
              "bench_b64_chol_kernel_summary.md", "bench_b64_sym_kernel_summary.md", "bench_b64_pca_kernel_summary.md",
-             "single_texture_kernel_summary.md", "gemm_mfma_counters.md", "sort_match4_sq_counters.md"):
+             "bench_b8_cdf_kernel_summary.md", "bench_b64_ownrotations_kernel_summary.md",
+             "single_texture_kernel_summary.md", "gemm_mfma_counters.md", "sort_match4_sq_counters.md",
+             "sort_rank4_phases.log", "sort_time_probe.log", "sort_columns_microbench.log", "normals_probe.log",
+             "batch_probe.log", "gram_probe.md", "ns_count_probe.md"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{pre}_{name}"))
 cdf = json.load(open(os.path.join(src, "pmc_traffic_cdf.json")))

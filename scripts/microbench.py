@@ -110,6 +110,9 @@ def main():
     if "loop" in only:
         xx = x.clone()
         report(tag + "_loop_cdf", timed(lambda: ops.ot_loop("cdf", xx, style, R32, Rt32), reps=3, warm=1))
+    if "loopsort" in only:  # the sort matcher as the hot loop runs it: range from the rotation GEMM's epilogue, hoisted style sort
+        xx = x.clone()
+        report(tag + "_loop_sort", timed(lambda: ops.ot_loop("sort", xx, style, R32, Rt32), reps=3, warm=1))
 
 
 if __name__ == "__main__":

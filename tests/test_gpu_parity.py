@@ -902,10 +902,11 @@ def test_ot_loop_pca_folded_vs_oracle_bit_exact(dev, mode, blend, Cf, k, n, ns, 
 @pytest.mark.parametrize("mode", ["chol", "pca", "cdf"])
 def test_ot_loop_pca_folded_vs_unfolded(dev, mode):
     """the folded call against project -> optex_ot_loop -> unproject on the device: the same map to fp32 round-off in the
-    smooth modes; in cdf mode (a discontinuous map) 99.5 % of the elements within 1e-4 of the range, the rest within a bin"""
+    smooth modes (three iterations); in cdf mode (a discontinuous map: one iteration, chains cannot be compared)
+    99.5 % of the elements within 1e-4 of the range, the rest within a bin"""
     from optimaltextures_amd import ops
     from optimaltextures_amd.driver import project_cm, unproject_cm
-    S, Cf, k, n, ns, iters = 3, 256, 181, 4096, 3072, 3
+    S, Cf, k, n, ns, iters = 3, 256, 181, 4096, 3072, (1 if mode == "cdf" else 3)
     rng = np.random.default_rng(len(mode))
     feat = cu(relu_feat(rng, S, Cf, n, scale=2.0, shift=0.3), dev)
     E = cu(np.linalg.qr(rng.standard_normal((Cf, k)))[0].astype(np.float32), dev)
