@@ -52,6 +52,18 @@ def rotations_per_segment(N: int, count: int, device, rngs):
     return R32.view(S, count, N, N), Rt32.view(S, count, N, N)
 
 
+_side_streams = {}
+
+
+def _generator_stream(device):
+    """ONE high-priority side stream per device for all generators (bench.py makes a DeviceNormals per step: a stream each would
+    be a hipStreamCreate / Destroy per step); the draws of different generators simply queue behind each other on it"""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(torch.device("cuda", key), priority=-1)
+    return _side_streams[key]
+
+
 class DeviceNormals:
     """numpy RandomState gaussian streams that live on the GPU (csrc/rotation.hip legacy_normals_kernel, ABI 7).
 
@@ -75,8 +87,8 @@ class DeviceNormals:
         words = lib.optex_mt19937_state_bytes() // 4
         self.device = torch.device(device)
         self.n = len(rngs)
-        # (a high-priority stream: the generator's lone wavefront per stream should not queue behind the main stream's launches)
-        self.stream = torch.cuda.Stream(self.device, priority=-1) if side_stream else None
+        # (a high-priority stream: the generator's one workgroup per stream should not queue behind the main stream's launches)
+        self.stream = _generator_stream(self.device) if side_stream else None
         self._queue = deque()   # prefetched draws in stream order: (N, count, normals, event)
         run = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         ints = all(isinstance(r, (int, np.integer)) and 0 <= int(r) < 2 ** 32 for r in rngs)

@@ -252,3 +252,31 @@ def test_encoder_out_shape_matches_the_convolutions(depth):
         with torch.inference_mode():
             f = enc.features(torch.rand(1, 3, h, w))
         assert tuple(f.shape[1:]) == enc.out_shape(h, w), (depth, h, w)
+
+
+def test_polar_method_is_parallel_over_four_word_attempts():
+    """The structure optex_legacy_normals (csrc/rotation.hip) relies on, checked against numpy itself on the host: an attempt of
+    numpy's legacy polar method consumes exactly four MT19937 words whether it is accepted or not, so the normals are a pure
+    function of the word stream — attempt j from words 4j .. 4j + 3, outputs = the accepted attempts in order, second value of
+    a pair first.  Evaluated that way (vectorised accept / reject, the host libm's scalar log like legacy_gauss uses) the
+    values equal RandomState.normal bit for bit, and the state after the draw is the state after exactly the words of the
+    last accepted attempt."""
+    import math
+    for seed, pairs in ((42, 4000), (7, 313)):
+        words_rng, ref = np.random.RandomState(seed), np.random.RandomState(seed)
+        w = words_rng.randint(0, 2 ** 32, size=4 * 2 * pairs, dtype=np.uint32).astype(np.uint64)   # raw tempered words
+        unit = lambda a, b: ((a >> 5).astype(np.float64) * 67108864.0 + (b >> 6).astype(np.float64)) / 9007199254740992.0
+        x1, x2 = 2.0 * unit(w[0::4], w[1::4]) - 1.0, 2.0 * unit(w[2::4], w[3::4]) - 1.0
+        r2 = x1 * x1 + x2 * x2
+        acc = ~((r2 >= 1.0) | (r2 == 0.0))
+        assert acc.sum() >= pairs
+        idx = np.flatnonzero(acc)[:pairs]
+        f = np.sqrt(-2.0 * np.array([math.log(v) for v in r2[idx]]) / r2[idx])
+        got = np.empty(2 * pairs)
+        got[0::2], got[1::2] = f * x2[idx], f * x1[idx]
+        assert np.array_equal(got, ref.normal(size=2 * pairs))
+        # the reference stream has consumed the words up to and including the last accepted attempt's — no more, no less
+        consumed = 4 * (int(idx[-1]) + 1)
+        probe = np.random.RandomState(seed)
+        probe.randint(0, 2 ** 32, size=consumed, dtype=np.uint32)
+        assert np.array_equal(probe.get_state()[1], ref.get_state()[1]) and probe.get_state()[2] == ref.get_state()[2]
