@@ -60,8 +60,13 @@ struct RsArgs {
 // k-steps test their rows, and a k-step entirely beyond K is branched over (uniform);  EXTRA: bias (badd) and content
 // blend in the epilogue (1), and the operand centring `B[k][i] - bsub[k]` of the linear modes' apply step as well (2:
 // KS more registers, one subtraction per fragment component, the same single rounding as the other kernels)
-template <int MT, int KS, int ROWSTAT, int EXTRA>
-__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 1))) void gemm_rs_kernel(RsArgs ra) {
+// WPE: wavefronts per SIMD (workgroup = 256 WPE threads, 64 MT WPE rows).  The library runs WPE = 1; WPE = 2 with MT = 2 is the
+// probe variant that lets one wave's epilogue and load waits hide under the other's MFMAs (scripts/Makefile, -DRS_WPE=2).
+#ifndef RS_WPE
+#define RS_WPE 1
+#endif
+template <int MT, int KS, int ROWSTAT, int EXTRA, int WPE = 1>
+__global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amdgpu_waves_per_eu(WPE, WPE))) void gemm_rs_kernel(RsArgs ra) {
     static_assert(KS % RS_DEPTH == 0, "the B ring keeps its phase across tiles");
     const GemmArgs& a = ra.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -289,6 +294,12 @@ int gemm_rs_parts(long n) { return (int)(n / RS_BN); }
 template <int MT, int KS>
 static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
     const GemmArgs& a = ra.g;
+#if RS_WPE == 2
+    if (MT == 4 && !a.bsub && !a.badd && !a.content && !a.rowstat) {   // probe build: 8 waves x 32 rows instead of 4 x 64
+        hipLaunchKernelGGL((gemm_rs_kernel<2, KS, 0, 0, 2>), grid, dim3(512), 0, st, ra);
+        return check_launch("gemm_rs_kernel");
+    }
+#endif
     if (a.rowstat && (a.bsub || a.badd || a.content)) {
         set_error("gemm_rs_kernel: row statistics cannot be combined with bsub / badd / content (gemm_rs_supported says so)");
         return OPTEX_E_UNSUPPORTED;
