@@ -18,6 +18,8 @@ for name in ("bench_default.json", "bench_b64_cdf_kernel_summary.md", "bench_b64
              "batch_probe.log", "gram_probe.md", "ns_count_probe.md"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{pre}_{name}"))
+if not os.path.exists(os.path.join(src, "pmc_traffic_cdf.json")):
+    sys.exit(0)   # a session without PMC passes: the files above are all there is to collect
 cdf = json.load(open(os.path.join(src, "pmc_traffic_cdf.json")))
 srt = json.load(open(os.path.join(src, "pmc_traffic_sort.json")))
 for n, d in (("cdf", cdf), ("sort", srt)):
