@@ -65,13 +65,16 @@ def _generator_stream(device):
 
 
 class DeviceNormals:
-    """numpy RandomState gaussian streams that live on the GPU (csrc/rotation.hip legacy_normals_kernel, ABI 7).
+    """numpy RandomState gaussian streams that live on the GPU (csrc/rotation.hip mt_accept_kernel + normals_emit_kernel,
+    optex_legacy_normals, ABI 7).
 
-    Built from numpy RandomState objects (or seeds): their get_state() tuples are copied to the device once, from then on
-    every draw is a kernel — one workgroup per stream — and the host never touches a normal again: no 17 ms of
+    Built from numpy RandomState objects (their get_state() tuples are copied to the device once) or from integer seeds
+    (seeded on the device); from then on every draw is a pair of kernels — one workgroup per stream walks the MT19937 words
+    and the accept / reject decisions, all CUs do the arithmetic — and the host never touches a normal again: no 17 ms of
     RandomState.normal and no 24 ms of pageable host-to-device copies per 52-iteration step (scripts/host_profile.py), and
-    64 per-texture streams advance side by side instead of on a host thread pool.  The values are numpy's (bit for bit
-    except where the device's log() differs from the host libm's by one unit in the last place).
+    64 per-texture streams advance side by side instead of on a host thread pool.  Words, decisions and state are numpy's
+    exactly; >= 99.8 % of the values equal RandomState.normal's bit for bit, the rest differ by <= 4 ulp (the device's log is
+    correctly rounded, glibc's is not quite).
 
     One stream: rotations(N, count) -> (R32 [count, N, N], Rt32), the whole batch shares the sequence like the reference's
     --batch (optex.py:168-170).  S streams: -> ([S, count, N, N], ...), one sequence per texture (the reference run once
@@ -89,7 +92,7 @@ class DeviceNormals:
         self.n = len(rngs)
         # (a high-priority stream: the generator's one workgroup per stream should not queue behind the main stream's launches)
         self.stream = _generator_stream(self.device) if side_stream else None
-        self._queue = deque()   # prefetched draws in stream order: (N, count, normals, event)
+        self._queue = deque()   # prefetched rotations in stream order: (N, count, (R32, Rt32), event)
         run = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         ints = all(isinstance(r, (int, np.integer)) and 0 <= int(r) < 2 ** 32 for r in rngs)
         stride = (int(rngs[1]) - int(rngs[0])) % 2 ** 32 if ints and self.n > 1 else 0
@@ -113,6 +116,8 @@ class DeviceNormals:
 
     def state(self, i: int = 0):
         """the stream's state as numpy's get_state() tuple (a host synchronisation: tests, hand-over back to the host)"""
+        if self.stream is not None:
+            self.stream.synchronize()
         w = self.states[i].cpu().numpy().view(np.uint32)
         return ("MT19937", w[:624].copy(), int(w[624]), int(w[625]), float(np.frombuffer(w[626:628].tobytes(), dtype=np.float64)[0]))
 

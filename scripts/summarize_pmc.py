@@ -40,12 +40,20 @@ def classify(name):
 def timed_rows(path, warmup):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "distribution_elementwise_grid_stride_kernel" in r["Kernel_Name"]]
-    starts.append(len(rows))
-    steps = [(a, b) for a, b in zip(starts[:-1], starts[1:])
-             if sum("householder_prep" in r["Kernel_Name"] for r in rows[a:b]) >= 5]
-    steps = steps[warmup:]
+    steps = step_intervals(rows)[warmup:]
     return [r for a, b in steps for r in rows[a:b]], len(steps)
+
+
+def step_intervals(rows):
+    """A bench step starts with the torch.rand() launches that create its pastiche batch (`distribution_elementwise...`, one per
+    texture, microseconds apart) and holds hundreds of kernels.  Since round 4 the rotation generator works on its own stream,
+    AHEAD of the main stream, so its kernels (householder_prep, ...) may carry timestamps of the previous step: a step is the
+    span from the first rand launch of a burst (> 2 ms after the previous rand launch) to the first of the next burst."""
+    rand = [i for i, r in enumerate(rows) if "distribution_elementwise_grid_stride_kernel" in r["Kernel_Name"]]
+    starts = [i for j, i in enumerate(rand)
+              if j == 0 or int(rows[i]["Start_Timestamp"]) - int(rows[rand[j - 1]]["Start_Timestamp"]) > 2_000_000]
+    starts.append(len(rows))
+    return [(a, b) for a, b in zip(starts[:-1], starts[1:]) if b - a >= 100]
 
 
 def main():

@@ -6,8 +6,8 @@ summary committed under profiles/.
 
 bench.py's warm-up step runs MIOpen's find mode (hundreds of trial convolutions), which would swamp a whole-run
 --stats table; this script therefore keeps only the TIMED steps: a step starts at the torch.rand() launch that creates
-its pastiche batch (`distribution_elementwise_grid_stride_kernel`) and contains >= 5 `householder_prep` launches (one
-per pass).  With --all the whole trace is summarised instead (micro-benchmarks).
+its pastiche batch (`distribution_elementwise_grid_stride_kernel`, a burst of one launch per texture) and holds at least 100
+kernels.  With --all the whole trace is summarised instead (micro-benchmarks).
 """
 import argparse
 import collections
@@ -35,12 +35,15 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     n_steps = 0
     if not args.all:
-        starts = [i for i, r in enumerate(rows) if "distribution_elementwise_grid_stride_kernel" in r["Kernel_Name"]]
+        # a step = from the first torch.rand() launch of a burst (one launch per texture, microseconds apart; > 2 ms after the
+        # previous rand launch) to the first of the next burst, at least 100 kernels.  (Up to round 3 a step was recognised by
+        # its >= 5 householder_prep launches; the rotation generator now runs AHEAD on its own stream, so those may carry
+        # timestamps of the previous step.)
+        rand = [i for i, r in enumerate(rows) if "distribution_elementwise_grid_stride_kernel" in r["Kernel_Name"]]
+        starts = [i for j, i in enumerate(rand)
+                  if j == 0 or int(rows[i]["Start_Timestamp"]) - int(rows[rand[j - 1]]["Start_Timestamp"]) > 2_000_000]
         starts.append(len(rows))
-        steps = []
-        for a, b in zip(starts[:-1], starts[1:]):
-            if sum("householder_prep" in r["Kernel_Name"] for r in rows[a:b]) >= 5:
-                steps.append((a, b))
+        steps = [(a, b) for a, b in zip(starts[:-1], starts[1:]) if b - a >= 100]
         steps = steps[args.warmup:]
         if not steps:
             sys.exit("no timed steps found in the trace")
