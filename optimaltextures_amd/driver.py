@@ -330,6 +330,7 @@ class OptimalTexture(torch.nn.Module):
         # whole batch, optex.py:168-170), or a list of one RandomState per texture (independent=True): every
         # texture then draws its own rotations — the batch equals B separate runs of the reference, seed for seed
         self.rng = None
+        self._group_streams = []  # forward_groups: one HIP stream per concurrent batch, reused across calls
 
     # -- optex.py:45-79, channel-major
     def _needs_resize(self, hw, size: int) -> bool:
@@ -489,7 +490,10 @@ class OptimalTexture(torch.nn.Module):
             raise ValueError("forward_groups: the groups share one rotation sequence")
         dev = pastiches[0].device
         main = torch.cuda.current_stream(dev)
-        streams = [torch.cuda.Stream(dev) for _ in pastiches]
+        # (the streams are kept: torch's caching allocator pools memory per stream, fresh streams would hipMalloc every tensor)
+        while len(self._group_streams) < len(pastiches):
+            self._group_streams.append(torch.cuda.Stream(dev))
+        streams = self._group_streams[:len(pastiches)]
         sides = self.prefetch_style_sides(pastiches[0].shape[-2:], styles, None) if self.use_pca else None
         if isinstance(self.rng, rotation.DeviceNormals):
             schedule = []
