@@ -390,25 +390,6 @@ def main():
                 result["textures_per_s_batch8"] = {
                     "value": round(6 * 8 / (time.perf_counter() - t0), 3),
                     "config": f"8 independent textures per step (config 4's per-GPU shard), hist_mode={args.hist_mode}, otherwise the headline configuration; 6 timed steps"}
-
-                def step8_two_streams():
-                    q = counter["step"]
-                    counter["step"] += 1
-                    tex.rng = rot(q)
-                    noise = otdist.texture_noise(q * 8, 8, (3, SIZE, SIZE), device, seed=args.seed)
-                    return tex.forward_groups([noise[:4], noise[4:]], [style])
-
-                for _ in range(2):
-                    step8_two_streams()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(6):
-                    step8_two_streams()
-                torch.cuda.synchronize()
-                result["textures_per_s_batch8"]["two_streams"] = round(6 * 8 / (time.perf_counter() - t0), 3)
-                result["textures_per_s_batch8"]["two_streams_config"] = (
-                    "the same 8 textures as two batches of 4 on two HIP streams (OptimalTexture.forward_groups): style side and "
-                    "rotations shared, the two batches fill each other's launch tails")
         if "fused" in args.other_modes.split(","):
             # labelled fast paths, NOT the headline.  cdf / sort: (m @ R^T) @ R' re-associated to m @ (R^T R'), one
             # feature-map GEMM per iteration instead of two; chol: the whole step as one affine map in un-rotated space

@@ -330,7 +330,6 @@ class OptimalTexture(torch.nn.Module):
         # whole batch, optex.py:168-170), or a list of one RandomState per texture (independent=True): every
         # texture then draws its own rotations — the batch equals B separate runs of the reference, seed for seed
         self.rng = None
-        self._group_streams = []  # forward_groups: one HIP stream per concurrent batch, reused across calls
 
     # -- optex.py:45-79, channel-major
     def _needs_resize(self, hw, size: int) -> bool:
@@ -476,75 +475,6 @@ class OptimalTexture(torch.nn.Module):
                 cf = cf - cf.mean() + torch.mean(sf)  # scalar re-centring (optex.py:76)
                 content_features.append(cf.contiguous())
         return pastiche, style_features, style_eigvs, content_features, style_hw
-
-    def forward_groups(self, pastiches: List[Tensor], styles: List[Tensor]) -> List[Tensor]:
-        """Several batches of independent textures that share ONE style and ONE rotation sequence (one rotation group of the
-        dist.py seeding rule), taken through the passes in lockstep with every batch on its OWN HIP stream.  A small batch —
-        BASELINE config 4 shards 8 textures per GPU — launches kernels of a handful of tiles per CU; two of them side by
-        side fill each other's tails.  The style side and the rotations are prepared once per (pass, layer) on the calling
-        stream and shared.  Texture synthesis only (no content image, no colour transfer, no style mixing, no multi-GPU hook);
-        the same arithmetic per texture as forward() on the concatenated batch — independent textures do not see each other."""
-        if not self.independent or len(styles) != 1 or self.style_sync is not None or self.color_transfer is not None:
-            raise ValueError("forward_groups: independent textures of one style, no colour transfer, no style_sync hook")
-        if isinstance(self.rng, (list, tuple)) or (isinstance(self.rng, rotation.DeviceNormals) and self.rng.n != 1):
-            raise ValueError("forward_groups: the groups share one rotation sequence")
-        dev = pastiches[0].device
-        main = torch.cuda.current_stream(dev)
-        # (the streams are kept: torch's caching allocator pools memory per stream, fresh streams would hipMalloc every tensor)
-        while len(self._group_streams) < len(pastiches):
-            self._group_streams.append(torch.cuda.Stream(dev))
-        streams = self._group_streams[:len(pastiches)]
-        sides = self.prefetch_style_sides(pastiches[0].shape[-2:], styles, None) if self.use_pca else None
-        if isinstance(self.rng, rotation.DeviceNormals):
-            schedule = []
-            for p in range(self.passes):
-                for li, encoder in enumerate(self.encoders):
-                    enc_index = li if self.index_by_position else 5 - encoder.depth
-                    c = int(sides[p][2][li].shape[1]) if self.use_pca else encoder.out_shape(16, 16)[0]
-                    schedule.append((c, layer_iters(self.iters_per_pass_and_layer, p, enc_index)))
-            self.rng.prefetch(schedule)
-        pastiches = list(pastiches)
-        for p in range(self.passes):
-            size = self.sizes[p]
-            resized = self._needs_resize(pastiches[0].shape[-2:], size)
-            if sides is not None and sides[p][0] == resized:
-                style_features, style_eigvs, _ = sides[p][1:]
-            else:
-                style_features, style_eigvs, _ = self._style_side(self._style_tensors(styles, size, resized))
-            for li, (encoder, decoder) in enumerate(zip(self.encoders, self.decoders)):
-                enc_index = li if self.index_by_position else 5 - encoder.depth
-                n_it = layer_iters(self.iters_per_pass_and_layer, p, enc_index)
-                c = int(style_features[li].shape[1])
-                R = None
-                if n_it > 0:
-                    R = (self.rng.rotations(c, n_it) if isinstance(self.rng, rotation.DeviceNormals)
-                         else rotation.rotations(c, n_it, dev, rng=self.rng))
-                ready = torch.cuda.Event()
-                ready.record(main)            # style side + rotations of this (pass, layer) are enqueued on the calling stream
-                shared = [style_features[li]] + ([style_eigvs[li]] if self.use_pca else []) + (list(R) if R is not None else [])
-                for g, st in enumerate(streams):
-                    st.wait_event(ready)
-                    for t in shared:          # made on the calling stream, read on this one: not to be recycled under it
-                        t.record_stream(st)
-                    with torch.cuda.stream(st):
-                        img = pastiches[g]
-                        if li == 0 and resized:
-                            img = resize(img, size=(size, size))
-                        feat = encoder.features(img)
-                        b, cf, h, w = feat.shape
-                        x = feat.reshape(b, cf, h * w)
-                        x = project_cm(x.contiguous(), style_eigvs[li]) if self.use_pca else x.contiguous()
-                        if n_it > 0:
-                            x = _shared_rotation_iterations(x, style_features[li], self.hist_mode, R[0], R[1], None, 0.0, False,
-                                                            self.fuse_rotations)
-                        if self.use_pca:
-                            x = unproject_cm(x, style_eigvs[li].t().contiguous())
-                        pastiches[g] = decoder.decode(x.view(b, -1, h, w))
-        for st in streams:                    # the results (and everything the groups still read) belong to the caller again
-            main.wait_stream(st)
-        for t in pastiches:
-            t.record_stream(main)
-        return pastiches
 
     def forward(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor] = None, verbose: bool = False,
                 on_layer=None):

@@ -945,29 +945,6 @@ def test_forward_with_folded_pca_equals_unfolded(dev):
     assert np.abs(outs[0] - outs[1]).max() <= 2e-3 * np.abs(outs[0]).max(), np.abs(outs[0] - outs[1]).max()
 
 
-def test_forward_groups_equals_forward_on_the_whole_batch(dev):
-    """OptimalTexture.forward_groups: two batches of independent textures of one rotation group on two HIP streams, style
-    side and rotations shared — every texture is the texture forward() makes of the concatenated batch (independent
-    textures do not see each other; the convolutions may pick other kernels at the smaller batch: fp32 round-off, chol mode)"""
-    from optimaltextures_amd.driver import OptimalTexture
-    g = torch.Generator().manual_seed(3)
-    style = torch.rand(1, 3, 96, 128, generator=g).to(dev)
-    noise = torch.rand(4, 3, 128, 128, generator=g).to(dev)
-    for no_pca in (True, False):
-        tex = OptimalTexture(size=128, iters=60, passes=2, hist_mode="chol", layers=(3, 2), independent=True, no_pca=no_pca).to(dev).eval()
-        with torch.inference_mode():
-            tex.rng = np.random.RandomState(21)
-            whole = tex.forward(noise.clone(), [style]).cpu().numpy()
-            tex.rng = np.random.RandomState(21)
-            parts = tex.forward_groups([noise[:2].clone(), noise[2:].clone()], [style])
-            torch.cuda.synchronize()
-            split = torch.cat(parts).cpu().numpy()
-        assert split.shape == whole.shape
-        assert np.abs(split - whole).max() <= 2e-3 * np.abs(whole).max(), np.abs(split - whole).max()
-    with pytest.raises(ValueError):
-        OptimalTexture(size=128, layers=(3,), independent=False).to(dev).forward_groups([noise], [style])
-
-
 # ================================================================================================ the numpy stream on the device
 def _ulps(a, b):
     return np.abs(a.view(np.int64) - b.view(np.int64))
