@@ -857,6 +857,47 @@ def test_ot_loop_is_hipgraph_capturable(dev, mode, C, blend):
         static_x.copy_(x0)
 
 
+def test_ot_loop_sort_with_non_finite_features_takes_the_fallback(dev):
+    """Inside optex_ot_loop the sort matcher gets its column range from the rotation GEMM's epilogue, whose min / max drop NaN:
+    a column with a NaN key (here: every column of one texture, after the rotation has spread one NaN pixel over all
+    channels) is still recognised per key, flagged before anything is stored, and swept by the radix kernel — the result is
+    the oracle's (totalOrder: NaN sorts last), the other texture is untouched by it."""
+    from optimaltextures_amd import ops
+    S, C, n, ns = 2, 256, 4096, 3072
+    rng = np.random.default_rng(77)
+    x = relu_feat(rng, S, C, n, scale=2.0, shift=0.3)
+    x[1, 5, 100] = np.nan
+    sty = relu_feat(rng, 1, C, ns, scale=1.5, shift=0.5)
+    lr = orc.LegacyRNG(9)
+    R = np.stack([orc.random_rotation(C, lr)]).astype(np.float32)
+    Rt = np.ascontiguousarray(R.transpose(0, 2, 1))
+    xd = cu(x, dev)
+    ops.ot_loop("sort", xd, cu(sty, dev), cu(R, dev), cu(Rt, dev))
+    got = xd.cpu().numpy()
+    for s in range(S):
+        rp, rs = orc.rotate_cm(x[s], R[0]), orc.rotate_cm(sty[0], R[0])
+        want = orc.unrotate_cm(orc.sort_match(rp, rs), R[0])
+        assert np.array_equal(np.isnan(got[s]), np.isnan(want)), f"segment {s}: NaN pattern"
+        ok = ~np.isnan(want)
+        assert np.array_equal(got[s][ok], want[ok]), f"segment {s}"
+    assert np.isfinite(got).all()   # the match replaces every key — a NaN ranks last and takes the style's largest values
+
+
+def test_ot_loop_pca_without_iterations_is_the_projector(dev):
+    """optex_ot_loop_pca with iters = 0: optex.py:110 then :120 with nothing in between, x <- (x @ E) @ E^T"""
+    from optimaltextures_amd import ops
+    S, Cf, k, n = 2, 64, 23, 1024
+    rng = np.random.default_rng(1)
+    feat = relu_feat(rng, S, Cf, n, scale=2.0)
+    E = np.linalg.qr(rng.standard_normal((Cf, k)))[0].astype(np.float32)
+    Et = np.ascontiguousarray(E.T)
+    xd = cu(feat, dev)
+    empty = torch.empty((0, k, k), dtype=torch.float32, device=dev)
+    ops.ot_loop_pca("cdf", xd, cu(E, dev), cu(Et, dev), cu(np.zeros((1, k, 8), np.float32), dev), empty, empty)
+    for s in range(S):
+        assert biteq(xd[s].cpu().numpy(), orc.gemm_tn(Et, orc.gemm_tn(E, feat[s])))
+
+
 # ================================================================================================ N1: PCA folded into the rotations
 @pytest.mark.parametrize("mode,blend,Cf,k,n,ns,iters", [("cdf", False, 64, 23, 1024, 768, 3), ("sort", False, 64, 23, 1024, 768, 2),
                                                         ("cdf", True, 64, 23, 1024, 768, 3), ("cdf", False, 256, 181, 4096, 3072, 2),
