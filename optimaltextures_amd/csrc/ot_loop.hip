@@ -576,8 +576,8 @@ extern "C" size_t optex_ot_loop_pca_ws_bytes(int mode, long n, long ns, int C, i
 extern "C" int optex_ot_loop_pca(int mode, float* x_full, int C_full, const float* eig, const float* eig_t, long n, int n_seg,
                                  const float* style, long ns, int src_n_seg, int C, const float* R32, const float* Rt32, int iters,
                                  const float* content, float strength, void* ws, size_t ws_bytes, void* stream) {
-    if (!x_full || !eig || !eig_t || !style || !R32 || !Rt32 || !ws || n <= 0 || ns <= 0 || C < 2 || C_full < C || n_seg <= 0 ||
-        iters < 0) {
+    if (!x_full || !eig || !eig_t || !style || (iters > 0 && (!R32 || !Rt32)) || !ws || n <= 0 || ns <= 0 || C < 2 || C_full < C ||
+        n_seg <= 0 || iters < 0) {
         set_error("optex_ot_loop_pca: bad argument (n=%ld ns=%ld C=%d C_full=%d n_seg=%d iters=%d)", n, ns, C, C_full, n_seg, iters);
         return OPTEX_E_ARG;
     }
