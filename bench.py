@@ -34,7 +34,12 @@ from optimaltextures_amd.util import get_iters_and_sizes, get_size, layer_iters,
 
 SIZE, PASSES, ITERS, LAYER = 512, 5, 500, 3
 PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS = 8000.0, 157.3  # MI355X_MICROARCH.md chip-level parameters
-MFMA_CLASSES = ("gemm_tn", "gram")
+MFMA_CLASSES = ("gemm_tn", "gram", "linalg_gemm")
+# sequential recurrences / one-workgroup factorizations: neither HBM- nor MFMA-bound, reported as "latency" without a fraction
+LATENCY_CLASSES = ("legacy_normals", "householder", "chol_inv", "ns_init", "cov_finalize", "col_mean")
+# classes whose launches go out on the rotation generator's SIDE stream (rotation.DeviceNormals.prefetch), concurrent with the
+# main stream's work: their HIP-event times are not part of the step's critical path
+SIDE_STREAM_CLASSES = ("legacy_normals", "householder")
 
 
 def synthetic_style(device, seed=0):
@@ -69,7 +74,11 @@ def pmc_traffic():
 
 def roofline_of(name, rec, traffic=None):
     ms, launches = rec["ms"], max(rec["launches"], 1)
-    if name in MFMA_CLASSES:
+    if name in LATENCY_CLASSES:
+        return {"kernel": name, "bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                "algorithmic_bytes": round(rec["bytes"] / launches), "launches": rec["launches"],
+                "avg_us": round(1e3 * ms / launches, 3), "side_stream": name in SIDE_STREAM_CLASSES}
+    if name in MFMA_CLASSES and rec["flops"] > 0:
         achieved, peak, unit, bound = rec["flops"] / (ms * 1e9), PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"
     else:
         achieved, peak, unit, bound = rec["bytes"] / (ms * 1e6), PEAK_HBM_GBS, "GB/s", "hbm"
@@ -222,6 +231,8 @@ def main():
     ap.add_argument("--host_rng", action="store_true",
                     help="draw the rotations' normals from numpy on the host and upload them (the round-1..3 path) instead of "
                          "advancing the same numpy streams on the GPU (rotation.DeviceNormals, optex_legacy_normals)")
+    ap.add_argument("--no_rng_ahead", action="store_true",
+                    help="draw a step's normals at the start of that step (round 4) instead of a step ahead on the side stream")
     ap.add_argument("--seed", type=int, default=0, help="job seed: texture i's noise and its rotation group's sequence are functions of (seed, i) only (dist.py)")
     ap.add_argument("--dry_run", action="store_true",
                     help="no GPU work: join the process group (gloo on CPU), walk the steps' texture shards, exercise the "
@@ -271,10 +282,31 @@ def main():
             return otdist.rotation_stream(args.seed, groups, device)
         return [otdist.rotation_rng(args.seed, g) for g in groups] if isinstance(groups, list) else otdist.rotation_rng(args.seed, groups)
 
+    ahead = {}
+
+    def stream_for(model, q, q_next):
+        """the rotation stream of group q, and — device streams without PCA, whose schedule is known from the layer lists —
+        the draws of the NEXT group enqueued behind it on the generator's side stream NOW: a group's sequence is a pure
+        function of (seed, q) (dist.py), so step k + 1's normals are drawn beside step k's convolutions instead of in front
+        of its own first loop (at 8 textures per step mt_accept_kernel's 12 ms of one CU were on the critical path of a
+        46 ms step).  Same values, same work inside the timed region: K steps draw K groups."""
+        if args.host_rng or args.no_rng_ahead or model.use_pca:
+            return rot(q)
+        sched = model.rotation_schedule()
+        rng = ahead.pop((id(model), q), None)
+        if rng is None:
+            rng = rot(q)
+            rng.prefetch(sched)
+        ahead.clear()
+        nxt = rot(q_next)
+        nxt.prefetch(sched)
+        ahead[(id(model), q_next)] = nxt
+        return rng
+
     def step(model):
         q = counter["step"] * world + rank
         counter["step"] += 1
-        model.rng = rot(q)
+        model.rng = stream_for(model, q, q + world)
         pastiche = otdist.texture_noise(q * B, B, (3, SIZE, SIZE), device, seed=args.seed)
         return model.forward(pastiche, [style])
 
@@ -318,7 +350,8 @@ def main():
                    "textures_per_gpu_per_step": B, "hist_mode": args.hist_mode, "parallelism": f"textures x{world}",
                    "rotation_sharing": f"one sequence per rotation group of {B} textures (= one rank's step), seeded by the group's global number",
                    "rotation_stream": "numpy RandomState gaussian stream, drawn on the host" if args.host_rng else
-                                      "numpy RandomState gaussian stream advanced on the GPU (optex_legacy_normals)"},
+                                      ("numpy RandomState gaussian stream advanced on the GPU (optex_legacy_normals)" +
+                                       ("" if args.no_rng_ahead else ", group q + 1 drawn on the side stream while group q is synthesised"))},
     }
     traffic, traffic_source = pmc_traffic()
     if traffic_source:
@@ -328,8 +361,10 @@ def main():
                          key=lambda r: -r["avg_us"] * r["launches"])
         result["roofline"] = {k: v for k, v in kernels[0].items()}
         result["kernels"] = kernels
-        hot_ms = sum(v["ms"] for v in prof.values()) / args.steps
-        result["hot_path_ms_per_step"] = round(hot_ms, 3)
+        side = () if args.host_rng else SIDE_STREAM_CLASSES
+        hot_ms = sum(v["ms"] for k, v in prof.items() if k not in side) / args.steps
+        result["hot_path_ms_per_step"] = round(hot_ms, 3)   # main-stream optex kernels only
+        result["side_stream_ms_per_step"] = round(sum(v["ms"] for k, v in prof.items() if k in side) / args.steps, 3)  # concurrent
         result["other_ms_per_step"] = round(ms_per_step - hot_ms, 3)  # VGG encode/decode, resizes, style encode, gaps
     # per-rank step times: the driver's scaling record can then show WHERE a loss comes from (a slow rank, or all of them)
     result["ms_per_step_by_rank"] = [round(1e3 * t / args.steps, 3) for t in otdist.all_gather_floats(elapsed_local, device)]
@@ -370,6 +405,25 @@ def main():
                                          "one launch of 256 workgroups, latency-bound by construction")
                     result["sort_kernels"] = sk
         result["textures_per_s_by_hist_mode"] = by_mode
+        result["textures_per_s_by_hist_mode_note"] = (
+            "chol / pca / sym rows run optex_ot_loop's DEFAULT association (fuse_rotations = 0): the step's last two products "
+            "(T hist_t + mu_s) R^T are ONE feature-map GEMM with the C x C matrix R T, and the style statistics are rotated as "
+            "matrices (R^T Sigma_s R) instead of rotating the style map — same maps to fp32 round-off, two feature-map GEMMs per "
+            "iteration instead of three; the literal three-GEMM sequence is textures_per_s_literal_linear_sequence")
+        if any(m in ("chol", "pca", "sym") for m in args.other_modes.split(",")):
+            # the literal sequence of optex.py:170-175 + histmatch.py:16-44 in the linear modes (fuse_rotations = 2): rotate,
+            # statistics, apply GEMM, rotate back as three separate feature-map GEMMs per iteration
+            lit = {}
+            with torch.inference_mode():
+                for mode in [m for m in ("chol", "pca", "sym") if m in args.other_modes.split(",")]:
+                    m = make_texturizer(mode, device, fuse_rotations=2)
+                    step(m)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    step(m)
+                    torch.cuda.synchronize()
+                    lit[mode] = round(B / (time.perf_counter() - t0), 3)
+            result["textures_per_s_literal_linear_sequence"] = lit
         if "batch8" in args.other_modes.split(",") and B != 8:
             # BASELINE config 4 as written shards 64 textures 8 per GPU: the per-GPU shard of that STRONG-scaling job on one
             # GPU (what `--total 64 --gpus 8` runs on every rank), several steps because one is short
@@ -377,7 +431,7 @@ def main():
                 def step8():
                     q = counter["step"]
                     counter["step"] += 1
-                    tex.rng = rot(q)
+                    tex.rng = stream_for(tex, q, q + 1)
                     return tex.forward(otdist.texture_noise(q * 8, 8, (3, SIZE, SIZE), device, seed=args.seed), [style])
 
                 for _ in range(2):

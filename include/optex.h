@@ -203,6 +203,10 @@ int optex_rotations_from_normals(const double* normals, int N, int count, double
  *   iterations in C x C algebra.  The covariance the next step needs follows analytically,
  *   cov(x') = M cov(x) M^T, so the feature map is read once for its statistics and once by the single GEMM that applies
  *   M_k ... M_1; agrees with the literal chain to accumulated fp32 round-off (tests/test_gpu_linalg.py).
+ * Scratch: optex_ot_loop_ws_bytes is a pure function of its arguments (no dependence on the current device).  In cdf mode
+ *   (and sort mode with ns <= 16384) with ONE rotation sequence for the batch and a shared style, the style side of all
+ *   iterations is prepared before the loop and kept in the scratch: iters rotated copies of the style, up to 1 GiB more
+ *   than a single copy; beyond that budget the style is rotated (and sorted) per iteration — same bits either way.
  * ------------------------------------------------------------------------------------------------- */
 size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int src_n_seg, int iters,
                               int fuse_rotations, long r_seg_stride);
@@ -218,7 +222,9 @@ int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, lon
  * The projection is FOLDED into the first rotation,  (feat @ E) @ R_0 = feat @ (E R_0), and — cdf / sort without a content
  * blend — the unprojection into the last rotation back,  (m @ R_l^T) @ E^T = m @ (E R_l)^T: two of the 2 * iters + 2
  * feature-map GEMMs of a (pass, layer) disappear.  Same products in another association: results agree with
- * project -> optex_ot_loop -> unproject to fp32 round-off (tests/test_gpu_parity.py), not bit for bit.  fuse_rotations = 0. */
+ * project -> optex_ot_loop -> unproject to fp32 round-off (tests/test_gpu_parity.py), not bit for bit.  fuse_rotations = 0.
+ * Arguments are validated before anything is enqueued.  The k-space state of the loop lives in the scratch only: with the
+ * unprojection folded (cdf / sort, content == NULL) nothing but x_full holds a result afterwards. */
 size_t optex_ot_loop_pca_ws_bytes(int mode, long n, long ns, int C, int C_full, int n_seg, int src_n_seg, int iters);
 int optex_ot_loop_pca(int mode, float* x_full, int C_full, const float* eig, const float* eig_t, long n, int n_seg,
                       const float* style, long ns, int src_n_seg, int C, const float* R32, const float* Rt32, int iters,

@@ -688,8 +688,12 @@ struct CdfWs {
     unsigned* part;     // per-block histograms    [n_seg, C, chunks_t + chunks_s, 256] (columns cut into chunks only)
     float* lut;         // edges, remapped, slope  [n_seg, C, 3, 256]
     size_t cols;
+    // sized for kMaxCuForWs compute units, NOT for the current device: optex_cdf_ws_bytes / optex_ot_loop_ws_bytes are pure
+    // functions of their arguments (include/optex.h), whatever device is current when a caller sizes its scratch.
+    // A launch cuts columns into at most max_chunks(cols, real CU count) <= this many chunks.
+    static constexpr int kMaxCuForWs = 512;
     static size_t part_words(size_t cols) {
-        const int k = max_chunks((int)cols, device_cu_count());
+        const int k = max_chunks((int)cols, kMaxCuForWs);
         return k <= 1 ? 0 : cols * 2 * (size_t)k * kBins;
     }
     static size_t bytes(int C, int n_seg) {
@@ -737,7 +741,7 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
                          const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st, const float* smn_given,
                          const float* smx_given, bool ws_clean) {
     CdfWs w(ws, C, n_seg);
-    const int ncols = C * n_seg, n_cu = device_cu_count();
+    const int ncols = C * n_seg, n_cu = device_cu_count() < CdfWs::kMaxCuForWs ? device_cu_count() : CdfWs::kMaxCuForWs;
     int rc;
     if (!ws_clean && (rc = device_fill_u32(w.done, 0u, w.cols, st))) return rc;
     const float *smn = smn_given, *smx = smx_given;

@@ -14,6 +14,7 @@
 // Roofline: 2*M*K*n flop against 4*(K + M)*n + 4*K*M bytes; at C = 256 the intensity is 64 flop/B, i.e.
 // MFMA-bound (157 TFLOP/s fp32 matrix peak); below C ~ 80 it turns HBM-bound.
 #include "gemm_args.h"
+#include "timeline.h"
 
 namespace optex {
 
@@ -357,12 +358,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int nchunks = (a.K + BK - 1) / BK;
+#ifdef OPTEX_TIMELINE
+    // slab: [0] = XCC id, [1] = real time at entry, [2] = entry, [3] = first chunk staged (behind the barrier), then per K chunk
+    // 4 stamps (global loads issued, MFMAs issued, LDS refilled, barrier passed), then stores issued, then the real time
+    tl_ptr tl = tl_begin(blockIdx.x * (NT / 64) + __builtin_amdgcn_readfirstlane(wave));
+    {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl_word(tl, (unsigned long long)(xcc & 0xff));
+    }
+    tl_stamp_real(tl);
+    tl_stamp(tl);
+#endif
     load_global(0);
     store_lds(0);
     __syncthreads();
+    TL_STAMP(tl);
     for (int kc = 0; kc < nchunks; kc++) {
         const int buf = kc & 1;
         if (kc + 1 < nchunks) load_global((kc + 1) * BK);
+#ifdef OPTEX_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        tl_stamp(tl);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         const float* as = &As[buf][kq * SA + wm * WM + l15];
         const float* bs = &Bs[buf][kq * SB + wn * WN + l15];
 #pragma unroll
@@ -378,8 +397,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
                 for (int tn = 0; tn < TN; tn++)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[tn], av[tm], acc[tm][tn], 0, 0, 0);
         }
+#ifdef OPTEX_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        tl_stamp(tl);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (kc + 1 < nchunks) store_lds(buf ^ 1);
+#ifdef OPTEX_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        tl_stamp(tl);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         __syncthreads();
+        TL_STAMP(tl);
     }
     // The MFMA is fed (B fragment, A fragment), i.e. it computes the TRANSPOSED 16 x 16 block: in its C/D layout
     // (col = lane & 15, row = 4 * (lane >> 4) + r) a lane then holds FOUR CONSECUTIVE PIXELS (r) of ONE channel (lane & 15),
@@ -461,6 +491,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm16_cm_kernel(GemmArgs a) {
             }
         }
     }
+#ifdef OPTEX_TIMELINE
+    __builtin_amdgcn_sched_barrier(0);
+    tl_stamp(tl);
+    tl_stamp_real(tl);
+    tl_end();
+#endif
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool BPM, bool OPM>
@@ -621,3 +657,5 @@ extern "C" int optex_gemm_tn(const float* At, long lda, long at_seg_stride, cons
     a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
     return gemm_tn_launch(a, b_layout, o_layout, as_stream(stream));
 }
+
+TL_DEFINE_SETTER(tl_set_lds)

@@ -23,12 +23,25 @@
 //     the 16 CONSECUTIVE pixels p0 + 16 g .. + 15 of channel m of each of its MT row tiles — four 16-byte stores each;
 //   * no barrier anywhere: the waves of a workgroup never exchange data.
 //
+// Round 5 (profiles/r05_gemm_timeline.md, s_memtime stamps per 4 k-steps):
+//   * THE MATRIX LIVES IN ACCUMULATION REGISTERS.  The register allocator used to keep ~3/4 of the 256 A fragments in AGPRs as
+//     "spill slots" and copy each one back with v_accvgpr_read_b32 (+ s_nop 1: VALU write -> MFMA read) in front of the four
+//     MFMAs that use it: k-steps whose fragments sat in VGPRs ran 2180 cycles per 64 MFMAs (0.94 of the pipe), the others
+//     2490-2620 (0.78-0.82) — the "13 points the loads cost" of round 3's NOLOAD probe were these copies (without the B ring
+//     the fragments fitted the VGPRs).  Every fragment is now DEFINED in an AGPR (v_accvgpr_write_b32 in the prologue): its
+//     live range has the AGPR class and the MFMA reads it from there (gfx950's MFMA takes SrcA / SrcB from either file).
+//   * the matrix arrives in 64 16-byte loads per wave instead of 256 4-byte ones: the wave's row tile t is the rows
+//     mw + MT i + t (i = lane & 15) — which 16 rows form an MFMA row tile is as free to choose as the pixel sub-tiles — so a
+//     lane's four fragments of a k-step are four consecutive floats.  The prologue took 29-43 thousand cycles (13-20 us: every
+//     CU of the chip asks the L2 for the same 256 KB in the same order, in 4-byte pieces), a third of a launch at 8 textures.
+//
 // Numerics: every output element is the k-ordered fmaf chain of the other GEMM kernels and of the oracle (a * b commutes
 // exactly; k-steps ascend, four k per step in MFMA order) — bit-identical.  Rows k >= K enter as exact zeros on BOTH
 // operands (a zero A fragment alone would turn a non-finite pad read into NaN).
 // Optional per-row statistics of the output (GemmArgs::rowstat, 1 = min / max, 2 = sum) are taken from the accumulators:
 // one partial per 64-pixel tile, [n_seg][n / 64][M].
 #include "gemm_args.h"
+#include "timeline.h"
 
 namespace optex {
 
@@ -65,13 +78,16 @@ struct RsArgs {
 #ifndef RS_WPE
 #define RS_WPE 1
 #endif
-template <int MT, int KS, int ROWSTAT, int EXTRA, int WPE = 1>
+// KFULL: K == 4 KS exactly (the launcher checks): no k-step is ragged, so the masks, selects and uniform branches of the last
+// RS_RAG k-steps disappear and the whole k-loop is one basic block (C = 256 and C = 128, the un-projected hot shapes)
+template <int MT, int KS, int ROWSTAT, int EXTRA, int WPE = 1, bool KFULL = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amdgpu_waves_per_eu(WPE, WPE))) void gemm_rs_kernel(RsArgs ra) {
     static_assert(KS % RS_DEPTH == 0, "the B ring keeps its phase across tiles");
+    constexpr int RAG = KFULL ? 0 : RS_RAG;   // the last RAG k-steps may lie (partly) beyond K
     const GemmArgs& a = ra.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    const int mw = wave * 16 * MT;
+    const int mw = wave * 16 * MT;  // 16 MT rows per wave; row tile t = the rows mw + MT i + t (i = lane & 15): a lane's MT rows are neighbours
     const int M = a.M, K = a.K;
 
     // A workgroup keeps ONE matrix: blockIdx.y selects a group of `segs_per_group` segments that share it (all of them
@@ -80,30 +96,65 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
     const long t0 = (long)blockIdx.y * T;
     const long tb = t0 + T * (long)blockIdx.x / (long)gridDim.x, te = t0 + T * ((long)blockIdx.x + 1) / (long)gridDim.x;
     if (tb >= te) return;
+#ifdef OPTEX_TIMELINE
+    // slab: [0] = XCC id | tiles << 8, [1] = real time at entry, [2] = entry, [3] = matrix + ring loads issued, then per tile
+    // 18 stamps (tile start, after k-steps 3, 7, ..., 63, stores issued), at the end the real time again
+    tl_ptr tl = tl_begin((blockIdx.y * gridDim.x + blockIdx.x) * 4 * WPE + wave);
+    {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl_word(tl, (unsigned long long)(xcc & 0xff) | ((unsigned long long)(te - tb) << 8));
+    }
+    tl_stamp_real(tl);
+    tl_stamp(tl);
+#endif
 
-    // the wave's slice of the matrix: fragment (t, ks) = At[4 ks + q][mw + 16 t + i].  Branch-free: rows / columns beyond
-    // K / M read a clamped (in-bounds) address and are zeroed by a select; one 32-bit offset per load on a uniform base.
+    // the wave's slice of the matrix: fragment (t, ks) = At[4 ks + q][mw + MT i + t] (row tile t = rows mw + MT i + t), kept in
+    // ACCUMULATION registers for the whole launch (see the header).  Branch-free: rows / columns beyond K / M read a clamped
+    // (in-bounds) address and are zeroed by a mask; one 32-bit offset per load on a uniform base.
     float af[MT][KS];
+    auto to_agpr = [](float v) {
+        float r;
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
+        return r;
+    };
     auto load_matrix = [&](int seg) {
         const rs_gfptr At = reinterpret_cast<rs_gfptr>(rs_uniform(a.At + (size_t)seg * a.at_ss));
         // (masks, not selects: a select of a loaded value against zero is turned into a branch around the load, and the
         // ragged rows then load two at a time behind s_waitcnt vmcnt(0))
+        if (MT == 4 && a.a_vec && (M & 3) == 0) {  // uniform: 16-byte loads, a lane's four rows are all inside M or all outside
+            const int m0 = mw + 4 * l15;
+            const unsigned mmask = m0 < M ? 0xffffffffu : 0u;
+            const unsigned moff = (unsigned)m0 & mmask;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const int k = 4 * ks + kq;
+                const unsigned kmask = (ks < KS - RAG || k < K) ? 0xffffffffu : 0u;
+                const unsigned koff = ((unsigned)k & kmask) * (unsigned)a.lda;
+                const rs_f4 v = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(At + koff + moff);
+#pragma unroll
+                for (int t = 0; t < MT; t++) af[t][ks] = to_agpr(__uint_as_float(__float_as_uint(v[t]) & kmask & mmask));
+                // 16 k-steps (16 loads, 64 registers) in flight at a time
+                if (ks % 16 == 15) __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         unsigned moff[MT], mmask[MT];
 #pragma unroll
         for (int t = 0; t < MT; t++) {
-            const int m = mw + 16 * t + l15;
+            const int m = mw + MT * l15 + t;
             mmask[t] = m < M ? 0xffffffffu : 0u;
             moff[t] = (unsigned)m & mmask[t];
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const int k = 4 * ks + kq;
-            const unsigned kmask = (ks < KS - RS_RAG || k < K) ? 0xffffffffu : 0u;
+            const unsigned kmask = (ks < KS - RAG || k < K) ? 0xffffffffu : 0u;
             const unsigned koff = ((unsigned)k & kmask) * (unsigned)a.lda;
 #pragma unroll
             for (int t = 0; t < MT; t++) {
                 const float v = At[koff + moff[t]];
-                af[t][ks] = __uint_as_float(__float_as_uint(v) & kmask & mmask[t]);
+                af[t][ks] = to_agpr(__uint_as_float(__float_as_uint(v) & kmask & mmask[t]));
             }
             // 16 k-steps (64 loads) in flight at a time: unfenced, the scheduler issues all 256 loads at once and spills
             if (ks % 16 == 15) __builtin_amdgcn_sched_barrier(0);
@@ -126,7 +177,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
     rs_gptr pk = tile_base(seg, pt);
     // load k-step ks (compile-time position) at the running pointer into `dst`, advance the pointer
     auto load_next = [&](int ks, rs_f4& dst) {
-        if (ks >= KS - RS_RAG) {
+        if (ks >= KS - RAG) {
             if (4 * ks < K) {  // uniform; a k-step entirely beyond K is neither loaded nor multiplied
                 const bool partial = 4 * ks + 4 > K;
                 // (the rows beyond K are zeroed where the k-step is CONSUMED: masking here would wait for the load at once)
@@ -138,7 +189,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
         pk += step_bytes;
     };
 
-    load_matrix(seg);
     // EXTRA == 2: the centring value bsub[4 ks + q] of every k-step travels through the ring beside its fragment (one more
     // dword load per k-step, L1 / L2 resident; KS registers of it kept for the whole launch spill).  The launcher keeps a
     // workgroup inside one segment when bsub varies with the segment.
@@ -147,7 +197,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
     auto load_sub = [&](int ks, float& dst) {
         if (EXTRA == 2) {
             const int k = 4 * ks + kq;
-            dst = sub[(ks < KS - RS_RAG || k < K) ? k : 0];
+            dst = sub[(ks < KS - RAG || k < K) ? k : 0];
         }
     };
 
@@ -158,8 +208,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
         load_next(d, br[d]);
         load_sub(d, bsr[EXTRA == 2 ? d : 0]);
     }
+    // (the matrix behind the first B fragments: their HBM latency passes while the matrix comes from the L2)
+    __builtin_amdgcn_sched_barrier(0);
+    load_matrix(seg);
+    TL_STAMP(tl);
 
     for (long tile = tb; tile < te; tile++) {
+        TL_STAMP(tl);
         int nseg = seg, npt = pt;
         if (tile + 1 < te) {  // (the last tile prefetches itself once more: in bounds, unused)
             npt = pt + 1;
@@ -172,7 +227,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
         for (int ks = 0; ks < KS; ks++) {
             rs_f4 b = br[ks % RS_DEPTH];
             if (EXTRA == 2) b = b - bsr[EXTRA == 2 ? ks % RS_DEPTH : 0];
-            if (ks >= KS - RS_RAG) {  // the k-step that K cuts: its rows beyond K enter as exact zeros
+            if (ks >= KS - RAG) {  // the k-step that K cuts: its rows beyond K enter as exact zeros
                 const unsigned pm = (4 * ks + 4 > K && !ok_p) ? 0u : 0xffffffffu;
 #pragma unroll
                 for (int j = 0; j < 4; j++) b[j] = __uint_as_float(__float_as_uint(b[j]) & pm);
@@ -183,7 +238,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
             load_next((ks + RS_DEPTH) % KS, br[ks % RS_DEPTH]);
             load_sub((ks + RS_DEPTH) % KS, bsr[EXTRA == 2 ? ks % RS_DEPTH : 0]);
 #endif
-            if (ks < KS - RS_RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
+            if (ks < KS - RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
 #pragma unroll
                 for (int t = 0; t < MT; t++) {
 #pragma unroll
@@ -196,15 +251,21 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
             // pin the software pipeline: unfenced, the machine scheduler sinks every load down to its consumer, eight
             // k-steps later, and the loop becomes load -> s_waitcnt vmcnt(0) -> 16 MFMAs
             __builtin_amdgcn_sched_barrier(0);
+#ifdef OPTEX_TIMELINE
+            if (ks % 4 == 3) {
+                tl_stamp(tl);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
 
-        // ---- epilogue.  acc[t][j][r] = OUT[m = mw + 16 t + l15][pixel p0 + 16 kq + 4 r + j]
+        // ---- epilogue.  acc[t][j][r] = OUT[m = mw + MT l15 + t][pixel p0 + 16 kq + 4 r + j]
         float* __restrict__ Op = a.O + (size_t)seg * a.o_ss + (size_t)pt * RS_BN + 16 * kq;
         const float* __restrict__ Cp = (EXTRA && a.content) ? a.content + (size_t)seg * a.o_ss + (size_t)pt * RS_BN + 16 * kq : nullptr;
         const float* __restrict__ badd = (EXTRA && a.badd) ? a.badd + (size_t)seg * a.badd_ss : nullptr;
 #pragma unroll
         for (int t = 0; t < MT; t++) {
-            const int m = mw + 16 * t + l15;
+            const int m = mw + MT * l15 + t;
             const bool ok = m < M;
             const size_t row = (size_t)(ok ? m : 0) * a.ldo;
             rs_f4 v[4];
@@ -267,7 +328,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
         }
         seg = nseg;
         pt = npt;
+#ifdef OPTEX_TIMELINE
+        __builtin_amdgcn_sched_barrier(0);
+        tl_stamp(tl);
+#endif
     }
+#ifdef OPTEX_TIMELINE
+    tl_stamp_real(tl);
+    tl_end();
+#endif
 }
 
 static inline bool rs_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -311,14 +380,26 @@ static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
             set_error("gemm_rs_kernel: bsub with M > 192 is not built (gemm_rs_supported says so)");
             return OPTEX_E_UNSUPPORTED;
         }
-    } else if (a.badd || a.content)
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1>), grid, dim3(256), 0, st, ra);
-    else if (a.rowstat == 1)
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0>), grid, dim3(256), 0, st, ra);
-    else if (a.rowstat == 2)
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0>), grid, dim3(256), 0, st, ra);
-    else
-        hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0>), grid, dim3(256), 0, st, ra);
+    } else if (a.badd || a.content) {
+        if ((MT == 4 && KS == 64) && a.K == 4 * KS)
+            hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1, 1, (MT == 4 && KS == 64)>), grid, dim3(256), 0, st, ra);
+        else
+            hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1>), grid, dim3(256), 0, st, ra);
+    } else {
+        // un-projected feature maps (C = 256, C = 128): K fills the instantiation exactly
+        constexpr bool HOT = (MT == 4 && KS == 64) || (MT == 2 && KS == 32);
+        const bool kfull = HOT && a.K == 4 * KS;
+        if (a.rowstat == 1) {
+            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0, 1, HOT>), grid, dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0>), grid, dim3(256), 0, st, ra);
+        } else if (a.rowstat == 2) {
+            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0, 1, HOT>), grid, dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0>), grid, dim3(256), 0, st, ra);
+        } else {
+            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0, 1, HOT>), grid, dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0>), grid, dim3(256), 0, st, ra);
+        }
+    }
     return check_launch("gemm_rs_kernel");
 }
 
@@ -350,3 +431,5 @@ int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
 }
 
 }  // namespace optex
+
+TL_DEFINE_SETTER(tl_set_rs)

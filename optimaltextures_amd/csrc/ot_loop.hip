@@ -581,6 +581,20 @@ extern "C" int optex_ot_loop_pca(int mode, float* x_full, int C_full, const floa
         set_error("optex_ot_loop_pca: bad argument (n=%ld ns=%ld C=%d C_full=%d n_seg=%d iters=%d)", n, ns, C, C_full, n_seg, iters);
         return OPTEX_E_ARG;
     }
+    // everything ot_loop_impl would refuse is refused HERE, before the E R_0 / (E R_l)^T products go onto the stream (ADVICE r4:
+    // a rejected call used to return after work had been enqueued)
+    if (mode < MODE_CDF || mode > MODE_SYM) {
+        set_error("optex_ot_loop_pca: mode %d (0 = cdf, 1 = sort, 2 = chol, 3 = pca, 4 = sym)", mode);
+        return OPTEX_E_ARG;
+    }
+    if (src_n_seg != 1 && src_n_seg != n_seg) {
+        set_error("optex_ot_loop_pca: style has %d segments, expected 1 or %d", src_n_seg, n_seg);
+        return OPTEX_E_ARG;
+    }
+    if (mode >= MODE_CHOL && C > 512) {
+        set_error("optex_ot_loop_pca: the linear modes support C <= 512 channels (got %d)", C);
+        return OPTEX_E_UNSUPPORTED;
+    }
     if (int rc = check_ws("optex_ot_loop_pca", ws, ws_bytes, optex_ot_loop_pca_ws_bytes(mode, n, ns, C, C_full, n_seg, src_n_seg, iters)))
         return rc;
     const size_t base = align_up(optex_ot_loop_ws_bytes(mode, n, ns, C, n_seg, src_n_seg, iters, 0, 0), 256);

@@ -446,6 +446,20 @@ class OptimalTexture(torch.nn.Module):
             out.append((resized, feats, [torch.empty((0, 0), device=f.device) for f in feats], hws[p]))
         return out
 
+    def rotation_schedule(self, sides=None):
+        """[(C, iterations), ...] of a forward() call in the order the loops ask for their rotations (pass-major, encoder-
+        minor, the colour-transfer draw last).  Without PCA it follows from the layer lists alone; with PCA the kept ranks
+        are those of `sides` (prefetch_style_sides), which must then be given."""
+        schedule = []
+        for p in range(self.passes):
+            for li, encoder in enumerate(self.encoders):
+                enc_index = li if self.index_by_position else 5 - encoder.depth
+                c = int(sides[p][2][li].shape[1]) if self.use_pca else encoder.out_shape(16, 16)[0]
+                schedule.append((c, layer_iters(self.iters_per_pass_and_layer, p, enc_index)))
+        if self.color_transfer == "opt":
+            schedule.append((3, 3))
+        return schedule
+
     def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int,
                       style_side=None):
         resized = self._needs_resize(pastiche.shape[-2:], size)
@@ -486,16 +500,12 @@ class OptimalTexture(torch.nn.Module):
                  if (self.style_sync is not None or self.use_pca) else None)
         if isinstance(self.rng, rotation.DeviceNormals):
             # device-side numpy stream(s): the draws of the whole call go out now, on the generator's side stream — they
-            # depend on nothing but the stream state and the (known) sizes, so they run beside the convolutions
-            schedule = []
-            for p in range(self.passes):
-                for li, encoder in enumerate(self.encoders):
-                    enc_index = li if self.index_by_position else 5 - encoder.depth
-                    c = int(sides[p][2][li].shape[1]) if self.use_pca else encoder.out_shape(16, 16)[0]
-                    schedule.append((c, layer_iters(self.iters_per_pass_and_layer, p, enc_index)))
-            if self.color_transfer == "opt":
-                schedule.append((3, 3))
-            self.rng.prefetch(schedule)
+            # depend on nothing but the stream state and the (known) sizes, so they run beside the convolutions.  A caller
+            # that knows its next job (bench.py, a sharded CLI run) may have enqueued them already, a call ahead
+            # (rotation_schedule + DeviceNormals.prefetch): then they ran beside the PREVIOUS call and nothing is drawn here.
+            schedule = self.rotation_schedule(sides)
+            if not self.rng.covers(schedule):
+                self.rng.prefetch(schedule)
         for p in range(self.passes):
             if verbose:
                 print(f"Pass {p}, size {self.sizes[p]}")

@@ -143,13 +143,39 @@ class DeviceNormals:
             return R32, Rt32
         return R32.view(self.n, count, N, N), Rt32.view(self.n, count, N, N)
 
+    # prefetched rotations kept alive at once (ADVICE r4): beyond this the remaining (pass, layer) entries of a schedule are
+    # drawn when they are asked for (still on the generator's stream, still in stream order)
+    PREFETCH_BYTES = 2 << 30
+
+    def pending(self):
+        """[(N, count), ...] of the prefetched rotations nobody has taken yet, in stream order"""
+        return [(n, c) for n, c, _, _ in self._queue]
+
+    def covers(self, schedule) -> bool:
+        """the pending prefetch is exactly the head of `schedule` (non-empty entries): a forward() call that finds its
+        schedule covered does not draw again — the draws were enqueued ahead of time, e.g. during the previous step"""
+        want = [(int(n), int(c)) for n, c in schedule if c > 0]
+        have = self.pending()
+        return len(have) > 0 and have == want[:len(have)]
+
+    def drop_pending(self):
+        """forget prefetched rotations (a forward() that raised midway, a schedule that changed): the stream stays where the
+        draws left it — the dropped values are consumed, exactly as if someone had asked for them and thrown them away"""
+        self._queue.clear()
+
     def prefetch(self, schedule):
         """schedule: [(N, count), ...] in the order the rotations will be asked for.  Draws AND Householder accumulations go
         out on the generator's stream now (with one sequence per texture the accumulations of a bench step are 3 328
-        rotations of 256^2, 27 ms that would otherwise sit between the convolutions and every OT loop)."""
+        rotations of 256^2, 27 ms that would otherwise sit between the convolutions and every OT loop).  Leftovers of an
+        earlier schedule are dropped first; at most PREFETCH_BYTES of rotations are kept ahead."""
+        self.drop_pending()
+        held = 0
         for N, count in schedule:
             if count > 0:
                 N, count = int(N), int(count)
+                held += 8 * self.n * count * N * N
+                if held > self.PREFETCH_BYTES:
+                    break
                 normals, ev = self.draw(count * ops.rotation_normals(N))
                 if self.stream is not None:
                     with torch.cuda.stream(self.stream):
@@ -166,15 +192,17 @@ class DeviceNormals:
         N, count = int(N), int(count)
         cur = torch.cuda.current_stream(self.device)
         if self._queue:
-            qn, qc, R, ev = self._queue.popleft()
-            if (qn, qc) != (N, count):
-                raise RuntimeError(f"DeviceNormals: prefetched rotations ({qc} of size {qn}) do not match the request "
-                                   f"({count} of size {N}): the stream has advanced past it")
-            if ev is not None:
-                cur.wait_event(ev)
-                for t in R:
-                    t.record_stream(cur)
-            return R
+            qn, qc, R, ev = self._queue[0]
+            if (qn, qc) == (N, count):
+                self._queue.popleft()
+                if ev is not None:
+                    cur.wait_event(ev)
+                    for t in R:
+                        t.record_stream(cur)
+                return R
+            # the caller left the prefetched schedule (another k after a re-fit, a call that raised midway): what was
+            # drawn ahead is dropped — consumed, like values asked for and thrown away — and this request is drawn now
+            self.drop_pending()
         normals, ev = self.draw(count * ops.rotation_normals(N))
         if ev is not None:
             cur.wait_event(ev)

@@ -52,6 +52,25 @@ def main():
             host_d = time.perf_counter() - t0
             torch.cuda.synchronize()
             devt = time.perf_counter() - t0
+            # device stream, group q + 1 drawn on the side stream while group q runs (bench.py's default since round 5)
+            def run_ahead(n, q0):
+                sched = tex.rotation_schedule()
+                rng = otdist.rotation_stream(0, q0, dev)
+                rng.prefetch(sched)
+                for q in range(q0, q0 + n):
+                    nxt = otdist.rotation_stream(0, q + 1, dev)
+                    nxt.prefetch(sched)
+                    tex.rng = rng
+                    tex.forward(otdist.texture_noise(q * B, B, (3, 512, 512), dev), [style])
+                    rng = nxt
+
+            run_ahead(2, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_ahead(steps, 2)
+            host_a = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            aht = time.perf_counter() - t0
             # the same steps with every rotation batch of the call served from a device-side cache
             cache, own = {}, rotation.rotations
 
@@ -80,6 +99,7 @@ def main():
         draw = time.perf_counter() - t0
         print(f"B = {B:3d}: host stream {B * steps / live:7.1f} textures/s ({1e3 * live / steps:6.1f} ms/step, host enqueue {1e3 * host / steps:6.1f} ms) | "
               f"device stream {B * steps / devt:7.1f} textures/s ({1e3 * devt / steps:6.1f} ms/step, host enqueue {1e3 * host_d / steps:6.1f} ms) | "
+              f"device stream a step ahead {B * steps / aht:7.1f} textures/s ({1e3 * aht / steps:6.1f} ms/step, host enqueue {1e3 * host_a / steps:6.1f} ms) | "
               f"cached rotations {B * steps / gpu:7.1f} textures/s ({1e3 * gpu / steps:6.1f} ms/step, host enqueue {1e3 * host_c / steps:6.1f} ms) | "
               f"drawing one step's 1.71 M normals on the host: {1e3 * draw:.1f} ms")
 

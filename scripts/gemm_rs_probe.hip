@@ -2,8 +2,12 @@
 // timed with HIP events, against the LDS-tiled kernels of gemm.hip on the same data; built in variants by scripts/Makefile
 // (-DRS_DEPTH_VALUE=..., -DRS_PROBE_NOLOAD).
 //   scripts/gemm_rs_probe_<variant>.bin [n_seg] [n] [M] [K] [reps] [1 = LDS-tiled kernels] [data: 0 gaussian, 1 zeros, 2 ReLU-like]
-#include "../optimaltextures_amd/csrc/gemm_rs.hip"
-#include "../optimaltextures_amd/csrc/gemm.hip"  // the LDS-tiled kernels, for comparison (argv[6] = 1)
+// (links csrc/gemm_rs.hip and csrc/gemm.hip as separate objects, compiled like the library's: scripts/Makefile)
+#include "../optimaltextures_amd/csrc/gemm_args.h"
+#ifndef RS_DEPTH_VALUE
+#define RS_DEPTH_VALUE 16
+#endif
+namespace optex { int device_cu_count(); }
 
 #include <random>
 #include <vector>
@@ -47,7 +51,7 @@ int main(int argc, char** argv) {
     double chk = 0;
     for (float v : ho) chk += v;
     const double us = 1e3 * ms / reps, tf = 2.0 * M * K * (double)n * S / (us * 1e6);
-    printf("%s ring %d%s, %s data: S=%d n=%ld M=%d K=%d  %.1f us  %.1f TFLOP/s  (%.3f of 157.3)  checksum %.6f\n", old ? "LDS-tiled kernel," : "R-stationary kernel,", optex::RS_DEPTH,
+    printf("%s ring %d%s, %s data: S=%d n=%ld M=%d K=%d  %.1f us  %.1f TFLOP/s  (%.3f of 157.3)  checksum %.6f\n", old ? "LDS-tiled kernel," : "R-stationary kernel,", RS_DEPTH_VALUE,
 #ifdef RS_PROBE_NOLOAD
            " NOLOAD",
 #else

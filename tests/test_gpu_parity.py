@@ -721,7 +721,10 @@ def test_optimal_transport_hip_equals_oracle_bit_exact(dev, golden, mode):
 
 @pytest.mark.parametrize("mode", ["cdf", "sort"])
 @pytest.mark.parametrize("S,Ss,C,n,ns,blend", [(2, 1, 32, 1024, 768, False), (1, 1, 16, 576, 560, True),
-                                                (3, 3, 8, 400, 300, True)])
+                                                (3, 3, 8, 400, 300, True),
+                                                # one style per segment: nothing is hoisted out of the loop, the style is rotated
+                                                # (and sorted) per iteration while the ranges still come from the GEMM epilogue
+                                                (2, 2, 256, 1024, 768, False)])
 def test_ot_loop_vs_oracle_bit_exact(dev, mode, S, Ss, C, n, ns, blend):
     """the fused hot loop (optex.py:112-117) over 4 iterations with explicit rotations"""
     from optimaltextures_amd import ops
@@ -785,6 +788,43 @@ def test_ot_loop_at_the_bench_shape_vs_oracle(dev, mode, C, blend):
             assert biteq(got[s], w), f"{mode} C={C} segment {s}: {np.count_nonzero(got[s] != w)} elements differ"
         else:
             assert maxrel(got[s], w) <= 2 * LIN_TOL, f"{mode} C={C} segment {s}: {maxrel(got[s], w):.2e}"
+
+
+@pytest.mark.parametrize("n,ns", [(9216, 13248), (12544, 18032), (6400, 9200)])
+@pytest.mark.parametrize("mode", ["cdf", "sort", "chol"])
+def test_ot_loop_at_the_small_batch_shapes_vs_oracle(dev, mode, n, ns):
+    """optex_ot_loop at BASELINE config 4's per-GPU shard: 8 independent segments of 96^2 / 112^2 / 80^2
+    pixels, 256 channels, the style at that pass's size — the launches where gemm.hip's small-batch routing hands the forward
+    rotation to the R-stationary kernel WITH the row-statistics epilogue (gemm_rs_kernel<4, 64, rowstat>: min / max for cdf
+    and sort, sums for chol) and the tail tiles of its balanced partition — against the oracle chain on two sampled
+    segments: bit-exact for cdf / sort, by tolerance for chol."""
+    from optimaltextures_amd import ops
+    S, C, iters = 8, 256, 2
+    rng = np.random.default_rng(n + len(mode))
+    x = relu_feat(rng, S, C, n, scale=2.0, shift=0.3)
+    sty = relu_feat(rng, 1, C, ns, scale=1.5, shift=0.5)
+    lr = orc.LegacyRNG(n)
+    R = np.stack([orc.random_rotation(C, lr) for _ in range(iters)]).astype(np.float32)
+    Rt = np.ascontiguousarray(R.transpose(0, 2, 1))
+    xd = cu(x, dev)
+    ops.ot_loop(mode, xd, cu(sty, dev), cu(R, dev), cu(Rt, dev))
+    got = xd.cpu().numpy()
+    assert np.isfinite(got).all()
+    for s in (0, 7):  # the first and the last segment: the head and the tail of the persistent workgroups' ranges
+        w = x[s]
+        for it in range(iters):
+            rp, rs = orc.rotate_cm(w, R[it]), orc.rotate_cm(sty[0], R[it])
+            if mode == "cdf":
+                m = orc.cdf_match(rp, rs)
+            elif mode == "sort":
+                m = orc.sort_match(rp, rs)
+            else:
+                m = orc.linear_match(rp, 1, rs, 1, mode)
+            w = orc.unrotate_cm(m, R[it])
+        if mode in ("cdf", "sort"):
+            assert biteq(got[s], w), f"{mode} n={n} segment {s}: {np.count_nonzero(got[s] != w)} elements differ"
+        else:
+            assert maxrel(got[s], w) <= 2 * LIN_TOL, f"{mode} n={n} segment {s}: {maxrel(got[s], w):.2e}"
 
 
 @pytest.mark.parametrize("mode,S,C,n,ns,blend", [("cdf", 3, 32, 1024, 768, False), ("sort", 2, 16, 576, 560, True),
@@ -1072,13 +1112,54 @@ def test_device_stream_rotations_equal_host_stream_rotations(dev, N, count):
     assert got.shape == host.shape and np.abs(got - host).max() <= 1.2e-7
     assert np.array_equal(Rt32.cpu().numpy(), got.transpose(0, 2, 1))
     assert np.mean(got == host) > 0.99
-    with pytest.raises(RuntimeError):
-        dn.rotations(N, 2)          # the prefetched draw was for ONE rotation
+    # a request that leaves the prefetched schedule (the prefetched draw was for ONE rotation): what was drawn ahead is dropped —
+    # consumed — and the request is drawn from where the stream stands (no raise, no stale hand-out)
+    twin = np.random.RandomState(31)
+    twin.normal(size=(count + 1) * (N * (N + 1) // 2 - 1))
+    want2 = rotation.rotations(N, 2, dev, rng=twin)[0].cpu().numpy()
+    got2 = dn.rotations(N, 2)[0].cpu().numpy()
+    assert not dn.pending() and np.abs(got2 - want2).max() <= 1.2e-7
     many = DeviceNormals([np.random.RandomState(31), np.random.RandomState(32)], dev)
     R2 = many.rotations(N, count)[0].cpu().numpy()
     assert R2.shape == (2, count, N, N) and np.abs(R2[0] - host).max() <= 1.2e-7
     other = rotation.rotations(N, count, dev, rng=np.random.RandomState(32))[0].cpu().numpy()
     assert np.abs(R2[1] - other).max() <= 1.2e-7
+
+
+def test_device_stream_drawn_a_step_ahead_is_the_same_stream(dev):
+    """bench.py draws rotation group q + 1 while group q is synthesised: a stream whose whole schedule was prefetched before
+    the call (DeviceNormals.covers -> forward() draws nothing) hands out the same rotations as one that draws at the call's
+    start and as one that draws on demand; a prefetch over PREFETCH_BYTES keeps only the head and draws the rest on demand"""
+    from optimaltextures_amd.driver import OptimalTexture
+    from optimaltextures_amd.rotation import DeviceNormals
+    tex = OptimalTexture(size=128, iters=60, passes=2, hist_mode="cdf", layers=(3, 2), no_pca=True, independent=True).to(dev).eval()
+    sched = tex.rotation_schedule()
+    assert [c for c, _ in sched] == [256, 128, 256, 128] and all(n > 0 for _, n in sched)
+    a, b, c = (DeviceNormals(1234, dev) for _ in range(3))
+    a.prefetch(sched)
+    assert a.covers(sched) and a.pending() == [(int(n), int(k)) for n, k in sched] and not b.covers(sched)
+    old = DeviceNormals.PREFETCH_BYTES
+    try:
+        DeviceNormals.PREFETCH_BYTES = 8 * sched[0][1] * 256 * 256 + 1   # room for the first entry only
+        c.prefetch(sched)
+        assert c.pending() == [(256, sched[0][1])] and c.covers(sched)
+    finally:
+        DeviceNormals.PREFETCH_BYTES = old
+    for n, k in sched:
+        ra, rb, rc = a.rotations(n, k), b.rotations(n, k), c.rotations(n, k)
+        torch.cuda.synchronize()
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[0], rc[0])
+    assert not a.pending() and not a.covers(sched)
+    # and forward() leaves a covered stream alone: afterwards the three streams stand at the same position
+    d = DeviceNormals(1234, dev)
+    d.prefetch(sched)
+    tex.rng = d
+    g = torch.Generator().manual_seed(0)
+    with torch.inference_mode():
+        out = tex.forward(torch.rand(1, 3, 128, 128, generator=g).to(dev), [torch.rand(1, 3, 96, 128, generator=g).to(dev)])
+    assert bool(torch.isfinite(out).all()) and not d.pending()
+    sa, sd = a.state(0), d.state(0)
+    assert np.array_equal(sa[1], sd[1]) and sa[2:4] == sd[2:4]
 
 
 def test_forward_with_device_rotation_stream_equals_host_stream(dev):
