@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round 5, session B: the R-stationary GEMM with the matrix in AGPRs + 16-byte matrix loads: parity, timeline, small batches.
+OUT=gpurun_out/r05b
+mkdir -p $OUT
+export TMPDIR=/tmp
+( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $OUT/pytest_gpu.log 2>&1
+tail -6 $OUT/pytest_gpu.log
+P=scripts/gemm_timeline_probe.bin
+( $P $OUT/tl_rs_b64.bin 0 64 16384 0 0
+  $P $OUT/tl_rs_b64_rowstat.bin 0 64 16384 1 0
+  $P $OUT/tl_rs_b64_zeros.bin 0 64 16384 0 1
+  scripts/gemm_timeline_probe_noload.bin $OUT/tl_rs_b64_noload.bin 0 64 16384 0 0
+  for N in 4096 9216; do $P $OUT/tl_rs_b8_$N.bin 0 8 $N 1 0; done ) > $OUT/timeline_probe.log 2>&1
+cat $OUT/timeline_probe.log
+python scripts/gemm_timeline_report.py $OUT/tl_rs_b64.bin $OUT/tl_rs_b64_rowstat.bin $OUT/tl_rs_b64_zeros.bin $OUT/tl_rs_b64_noload.bin $OUT/tl_rs_b8_4096.bin $OUT/tl_rs_b8_9216.bin > $OUT/gemm_timeline.md 2> $OUT/report.err
+rm -f $OUT/tl_*.bin
+( for N in 4096 6400 9216 12544 16384; do scripts/gemm_rs_probe_d16.bin 8 $N 256 256 50 0 0; scripts/gemm_rs_probe_d16.bin 8 $N 256 256 50 1 0; done
+  for D in 0 2 1; do scripts/gemm_rs_probe_d16.bin 64 16384 256 256 20 0 $D; scripts/gemm_rs_probe_d16.bin 64 16384 256 256 20 1 $D; done
+  scripts/gemm_rs_probe_d16.bin 64 16384 181 181 20 0 0; scripts/gemm_rs_probe_d16.bin 64 16384 192 192 20 0 0; scripts/gemm_rs_probe_d16.bin 64 16384 128 128 20 0 0
+  scripts/gemm_rs_probe_d16.bin 64 4096 256 256 20 0 0; scripts/gemm_rs_probe_d16.bin 64 4096 256 256 20 1 0
+  scripts/gemm_rs_probe_noload.bin 64 16384 256 256 20 0 0 ) > $OUT/gemm_probe.log 2>&1
+cat $OUT/gemm_probe.log
+( timeout 600 python scripts/batch_probe.py 8 64 ) > $OUT/batch_probe.log 2>&1
+tail -3 $OUT/batch_probe.log | cut -c1-600
+grep -v "^| k-steps [0-9]*\.\.[0-9]* " $OUT/gemm_timeline.md | head -120
