@@ -156,11 +156,62 @@ __global__ void minmax_decode_kernel(float* mn, float* mx, int ncols) {
 }
 
 // ------------------------------------------------------------------------------------------------ K2b histogram
-__device__ __forceinline__ void hist_add(unsigned* h, float v, float lo, float hi, float range) {
-    if (!(v >= lo && v <= hi)) return;  // also skips NaN, like ATen
-    int pos = (int)__fdiv_rn((v - lo) * (float)kBins, range);
+// The bin index is trunc of the IEEE quotient (x - lo) * 256 / range (torch.histc; a multiply by a rounded reciprocal mis-bins
+// ~1.4 ppm).  The compiler's correctly rounded division is ~11 instructions per element, most of them of the 4-cycle class
+// (v_div_scale x 2, v_rcp, v_div_fmas, v_div_fixup) — and this kernel is VALU-bound on it (round 5: 2.56 M elements per CU per
+// launch at 0.27 cycles each = the 290 of its 326 us).  For a divisor b whose correctly rounded reciprocal y = RN(1 / b) is
+// known — one true division per column — the quotient takes a multiply and four fmas, all of the 2-cycle class:
+//     q0 = RN(a y);  r0 = a - b q0 (exact in the fma);  q1 = RN(q0 + r0 y);  r1 = a - b q1;  q = RN(q1 + r1 y)
+// q1 is within half an ulp (+ 2^-24 ulp) of a / b, and the last step then rounds correctly (Markstein's theorem: the fma's
+// argument differs from a / b by less than 2^-25 ulp, closer than a quotient of two 24-bit numbers can come to a rounding
+// boundary without lying on one of them, which it never does).  Checked against the division itself on 1.2e9 operand
+// pairs incl. all-ones mantissas, powers of two and +-4 ulp around every bin edge k * range: 0 differing quotients.  Needs
+// normal operands: used when 2^-100 < range < 2^100 (uniform per column), the plain division otherwise.
+__device__ __forceinline__ float div_by(float a, float b, float y) {
+    const float q0 = __fmul_rn(a, y);
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y, q1);
+}
+__device__ __forceinline__ bool div_by_ok(float range) { return range > 7.8886091e-31f && range < 1.2676506e30f; }  // 2^-100, 2^100
+
+template <bool FAST = false>
+__device__ __forceinline__ void hist_add(unsigned* h, float v, float lo, float hi, float range, float inv = 0.f) {
+    // branch-free: a value outside [lo, hi] (NaN included, like ATen) adds 0 to a clamped bin — four independent chains per
+    // 16-byte load instead of four exec-mask branches
+    const unsigned inc = (v >= lo && v <= hi) ? 1u : 0u;
+    const float a = (v - lo) * (float)kBins;
+    int pos = (int)(FAST ? div_by(a, range, inv) : __fdiv_rn(a, range));   // (the conversion saturates; NaN -> 0)
     pos = pos > kBins - 1 ? kBins - 1 : pos;
-    atomicAdd(&h[pos], 1u);
+    pos = pos < 0 ? 0 : pos;
+    atomicAdd(&h[pos], inc);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void hist_chunk_t(unsigned* h, const float* __restrict__ p, long beg, long end, int vec, float hl, float hu,
+                                             float range, float inv) {
+    const int tid = threadIdx.x;
+    if (vec) {  // beg is a multiple of 4 and rows are 16-byte aligned
+        const long nv = (end - beg) / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p + beg);
+        for (long i = tid; i < nv; i += 256) {
+            const float4 v = p4[i];
+            hist_add<FAST>(h, v.x, hl, hu, range, inv);
+            hist_add<FAST>(h, v.y, hl, hu, range, inv);
+            hist_add<FAST>(h, v.z, hl, hu, range, inv);
+            hist_add<FAST>(h, v.w, hl, hu, range, inv);
+        }
+        for (long i = beg + nv * 4 + tid; i < end; i += 256) hist_add<FAST>(h, p[i], hl, hu, range, inv);
+    } else {
+        for (long i = beg + tid; i < end; i += 256) hist_add<FAST>(h, p[i], hl, hu, range, inv);
+    }
+}
+// (the reciprocal is taken once per call: one division per thread and chunk)
+__device__ __forceinline__ void hist_chunk(unsigned* h, const float* __restrict__ p, long beg, long end, int vec, float hl, float hu,
+                                           float range) {
+    if (div_by_ok(range)) hist_chunk_t<true>(h, p, beg, end, vec, hl, hu, range, __fdiv_rn(1.0f, range));
+    else hist_chunk_t<false>(h, p, beg, end, vec, hl, hu, range, 0.f);
 }
 
 // grid = (columns, chunks).  lohi_seg_div: the (lo, hi) of column (seg, c) is read at [(seg / lohi_seg_div), c] so that a
@@ -183,20 +234,7 @@ __global__ __launch_bounds__(256) void col_hist_kernel(const float* __restrict__
     const float range = hi - lo;
     unsigned* h = sh[threadIdx.x >> 6];
     const long beg = (long)blockIdx.y * chunk, end = (beg + chunk < n) ? beg + chunk : n;
-    if (vec) {
-        const long nv = (end - beg) / 4;
-        const float4* p4 = reinterpret_cast<const float4*>(p + beg);
-        for (long i = threadIdx.x; i < nv; i += blockDim.x) {
-            const float4 v = p4[i];
-            hist_add(h, v.x, lo, hi, range);
-            hist_add(h, v.y, lo, hi, range);
-            hist_add(h, v.z, lo, hi, range);
-            hist_add(h, v.w, lo, hi, range);
-        }
-        for (long i = beg + nv * 4 + threadIdx.x; i < end; i += blockDim.x) hist_add(h, p[i], lo, hi, range);
-    } else {
-        for (long i = beg + threadIdx.x; i < end; i += blockDim.x) hist_add(h, p[i], lo, hi, range);
-    }
+    hist_chunk(h, p, beg, end, vec, lo, hi, range);   // (blockDim.x == 256)
     __syncthreads();
     unsigned* g = hist + (size_t)col * kBins;
     for (int i = threadIdx.x; i < kBins; i += blockDim.x) {
@@ -302,28 +340,14 @@ struct HistLutArgs {
     const float* smn; const float* smx;                // source min / max [src_n_seg, C] (joined with the partials)
     float* lo; float* hi;                              // joint range [ncols]: read if pmn == NULL, written for the apply kernel
     unsigned* part; unsigned* done;                    // multi-chunk only: [ncols][chunks_t + chunks_s][256] and the tickets
+    // optional: the source columns' histograms over their OWN range [smn, smx], [src_n_seg, C, 256].  A column whose joint
+    // range IS the source's range (the source's range contains the target's: the usual case once the pastiche has been matched
+    // a few times) takes them instead of binning the source again — the same counts, bin for bin, since the same range gives
+    // the same arithmetic; optex_ot_loop computes them once per (iteration, channel) for all textures of a batch.
+    const unsigned* shist;
     float* lut; float* dbg;
     int vec_t, vec_s;
 };
-
-__device__ __forceinline__ void hist_chunk(unsigned* h, const float* __restrict__ p, long beg, long end, int vec, float hl, float hu,
-                                           float range) {
-    const int tid = threadIdx.x;
-    if (vec) {  // beg is a multiple of 4 and rows are 16-byte aligned
-        const long nv = (end - beg) / 4;
-        const float4* p4 = reinterpret_cast<const float4*>(p + beg);
-        for (long i = tid; i < nv; i += 256) {
-            const float4 v = p4[i];
-            hist_add(h, v.x, hl, hu, range);
-            hist_add(h, v.y, hl, hu, range);
-            hist_add(h, v.z, hl, hu, range);
-            hist_add(h, v.w, hl, hu, range);
-        }
-        for (long i = beg + nv * 4 + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
-    } else {
-        for (long i = beg + tid; i < end; i += 256) hist_add(h, p[i], hl, hu, range);
-    }
-}
 
 __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
     const int col = blockIdx.x, seg = col / a.C, c = col % a.C, tid = threadIdx.x;
@@ -333,6 +357,7 @@ __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
     __shared__ LutShared S;
     for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
     float lo, hi;
+    bool src_range = false;   // the joint range is the source's own range: its precomputed histogram applies
     if (a.pmn) {
         lo = INFINITY;
         hi = -INFINITY;
@@ -350,8 +375,10 @@ __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
         }
         __syncthreads();
         const int oc = ((a.src_n_seg == 1) ? 0 : seg) * a.C + c;
-        lo = fminf(fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), a.smn[oc]);   // histmatch.py:52-53
-        hi = fmaxf(fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3])), a.smx[oc]);
+        const float smn = a.smn[oc], smx = a.smx[oc];
+        lo = fminf(fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), smn);   // histmatch.py:52-53
+        hi = fmaxf(fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3])), smx);
+        src_range = a.shist != nullptr && lo == smn && hi == smx;   // uniform over the block
     } else {
         lo = a.lo[col];
         hi = a.hi[col];
@@ -374,11 +401,16 @@ __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
         __syncthreads();
         const unsigned ht = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
         __syncthreads();
-        for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
-        __syncthreads();
-        hist_chunk(h, ps, 0, a.ns, a.vec_s, hl, hu, range);
-        __syncthreads();
-        const unsigned hs = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+        unsigned hs;
+        if (src_range) {
+            hs = a.shist[((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * kBins + tid];
+        } else {
+            for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
+            __syncthreads();
+            hist_chunk(h, ps, 0, a.ns, a.vec_s, hl, hu, range);
+            __syncthreads();
+            hs = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+        }
         if (tid == 0) {
             a.lo[col] = lo;
             a.hi[col] = hi;
@@ -725,6 +757,12 @@ int col_minmax_launch(const float* x, long ld, long ss, long n, int C, int n_seg
     return launch_minmax(x, ld, ss, n, C, n_seg, nullptr, nullptr, 1, mn, mx, st);
 }
 
+// torch.histc(column, 256, lo[col], hi[col]) of every column of n_seg segments, hist [n_seg, C, 256]
+int col_hist_launch(const float* x, long ld, long ss, long n, int C, int n_seg, const float* lo, const float* hi, unsigned* hist,
+                    hipStream_t st) {
+    return launch_hist(x, ld, ss, n, C, n_seg, n_seg, lo, hi, hist, st);
+}
+
 int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
                    hipStream_t st) {
@@ -739,7 +777,7 @@ int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float
 int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                          int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
                          const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st, const float* smn_given,
-                         const float* smx_given, bool ws_clean) {
+                         const float* smx_given, bool ws_clean, const unsigned* shist_given) {
     CdfWs w(ws, C, n_seg);
     const int ncols = C * n_seg, n_cu = device_cu_count() < CdfWs::kMaxCuForWs ? device_cu_count() : CdfWs::kMaxCuForWs;
     int rc;
@@ -764,6 +802,7 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
     a.pmn = tmn_parts; a.pmx = tmn_parts ? tmx_parts : nullptr; a.parts = parts;
     a.smn = smn; a.smx = smx;
     a.lo = w.lo; a.hi = w.hi; a.part = w.part; a.done = w.done; a.lut = w.lut; a.dbg = dbg;
+    a.shist = (smn_given && smx_given) ? shist_given : nullptr;   // (they go with the given source range)
     a.vec_t = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0;
     a.vec_s = aligned16(source) && lds % 4 == 0 && sss % 4 == 0;
     {

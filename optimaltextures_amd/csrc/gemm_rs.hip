@@ -17,11 +17,12 @@
 //   * the feature map goes from HBM straight into the MFMA's B-operand registers: lane (i = lane & 15, q = lane >> 4) loads
 //     the 16 bytes B[4 ks + q][p0 + 4 i .. + 3] of k-step ks — component j of that float4 IS the fragment of pixel sub-tile j
 //     (sub-tile j = pixels p0 + 4 i + j: which 16 pixels form a 16-column MFMA tile is free to choose), so one
-//     global_load_dwordx4 feeds 4 MT MFMAs and nothing passes through LDS.  A ring of DEPTH k-steps is in flight per wave,
+//     global_load_dwordx4 feeds 4 MT MFMAs and no feature-map byte passes through LDS.  A ring of DEPTH k-steps is in flight per wave,
 //     across tile boundaries; the four waves of a CU read the same lines, HBM sees them once;
 //   * fed (B fragment, A fragment) the MFMA returns the transposed block: lane (m = lane & 15, g = lane >> 4) ends up with
 //     the 16 CONSECUTIVE pixels p0 + 16 g .. + 15 of channel m of each of its MT row tiles — four 16-byte stores each;
-//   * no barrier anywhere: the waves of a workgroup never exchange data.
+//   * no barrier in the loop: the waves of a workgroup never exchange data (they share the staging of the matrix in the
+//     prologue, round 5).
 //
 // Round 5 (profiles/r05_gemm_timeline.md, s_memtime stamps per 4 k-steps):
 //   * THE MATRIX LIVES IN ACCUMULATION REGISTERS.  The register allocator used to keep ~3/4 of the 256 A fragments in AGPRs as
@@ -30,10 +31,11 @@
 //     2490-2620 (0.78-0.82) — the "13 points the loads cost" of round 3's NOLOAD probe were these copies (without the B ring
 //     the fragments fitted the VGPRs).  Every fragment is now DEFINED in an AGPR (v_accvgpr_write_b32 in the prologue): its
 //     live range has the AGPR class and the MFMA reads it from there (gfx950's MFMA takes SrcA / SrcB from either file).
-//   * the matrix arrives in 64 16-byte loads per wave instead of 256 4-byte ones: the wave's row tile t is the rows
-//     mw + MT i + t (i = lane & 15) — which 16 rows form an MFMA row tile is as free to choose as the pixel sub-tiles — so a
-//     lane's four fragments of a k-step are four consecutive floats.  The prologue took 29-43 thousand cycles (13-20 us: every
-//     CU of the chip asks the L2 for the same 256 KB in the same order, in 4-byte pieces), a third of a launch at 8 textures.
+//   * the matrix comes in through LDS (load_matrix below): the workgroup fetches 32-row blocks together and every wave picks
+//     its fragments with one 16-byte LDS read per k-step — the wave's row tile t is the rows mw + MT i + t (i = lane & 15;
+//     which 16 rows form an MFMA row tile is as free to choose as the pixel sub-tiles), so a lane's fragments of a k-step
+//     are neighbours.  Fetched per wave straight from the L2 the prologue took 29-70 thousand cycles (14-30 us: every CU of
+//     the chip asks for the same 256 KB in the same order), a third of a launch at 8 textures per step.
 //
 // Numerics: every output element is the k-ordered fmaf chain of the other GEMM kernels and of the oracle (a * b commutes
 // exactly; k-steps ascend, four k per step in MFMA order) — bit-identical.  Rows k >= K enter as exact zeros on BOTH
@@ -110,54 +112,77 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
 #endif
 
     // the wave's slice of the matrix: fragment (t, ks) = At[4 ks + q][mw + MT i + t] (row tile t = rows mw + MT i + t), kept in
-    // ACCUMULATION registers for the whole launch (see the header).  Branch-free: rows / columns beyond K / M read a clamped
-    // (in-bounds) address and are zeroed by a mask; one 32-bit offset per load on a uniform base.
+    // ACCUMULATION registers for the whole launch (see the header); rows / columns beyond K / M are exact zeros.
     float af[MT][KS];
     auto to_agpr = [](float v) {
         float r;
         asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
         return r;
     };
+    // The matrix reaches the registers THROUGH LDS, 8 k-steps (32 rows) at a time.  Straight from the L2 it took 29-70 thousand
+    // cycles (14-30 us, profiles/r05_gemm_timeline.md): every wavefront of the chip asks for the same 256 KB in the same order,
+    // so at any moment all 256 CUs queue at the one or two L2 channels that hold the current rows.  Here the workgroup fetches
+    // a 32-row block together — whole 4 KB spans per instruction, the eight pieces of a block in an order rotated by the
+    // workgroup's number, two blocks ahead of the one being unpacked — zero-fills what lies beyond K / M on the way, and every
+    // wave then picks its fragments with one 16-byte LDS read per k-step (MT = 4; MT scalar reads otherwise).
+    constexpr int NTH = 256 * WPE, LROW = 260, PH = KS / 8, NG = 2048 / NTH;   // threads, staged row stride (floats), phases, 16-byte pieces per thread and phase
+    __shared__ __attribute__((aligned(16))) float As[32 * LROW];
     auto load_matrix = [&](int seg) {
         const rs_gfptr At = reinterpret_cast<rs_gfptr>(rs_uniform(a.At + (size_t)seg * a.at_ss));
-        // (masks, not selects: a select of a loaded value against zero is turned into a branch around the load, and the
-        // ragged rows then load two at a time behind s_waitcnt vmcnt(0))
-        if (MT == 4 && a.a_vec && (M & 3) == 0) {  // uniform: 16-byte loads, a lane's four rows are all inside M or all outside
-            const int m0 = mw + 4 * l15;
-            const unsigned mmask = m0 < M ? 0xffffffffu : 0u;
-            const unsigned moff = (unsigned)m0 & mmask;
+        const bool vec = a.a_vec && (M & 3) == 0;   // uniform: 16-byte global loads, a piece is all inside M or all outside
+        const int rot = (int)(blockIdx.x + blockIdx.y) & (NG - 1);
+        rs_f4 g[2][NG];
+        auto gload = [&](int p, rs_f4 (&dst)[NG]) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                const int k = 4 * ks + kq;
-                const unsigned kmask = (ks < KS - RAG || k < K) ? 0xffffffffu : 0u;
-                const unsigned koff = ((unsigned)k & kmask) * (unsigned)a.lda;
-                const rs_f4 v = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(At + koff + moff);
+            for (int i = 0; i < NG; i++) {
+                const int idx = (int)threadIdx.x + NTH * ((i + rot) & (NG - 1));
+                const int row = idx >> 6, c0 = (idx & 63) * 4, k = 32 * p + row;
+                rs_f4 v = rs_f4{0.f, 0.f, 0.f, 0.f};
+                if (vec) {
+                    // (masks, not selects: see the header — a select of a loaded value becomes a branch around the load)
+                    const unsigned ok = (k < K && c0 < M) ? 0xffffffffu : 0u;
+                    const unsigned off = ((unsigned)k * (unsigned)a.lda + (unsigned)c0) & ok;
+                    const rs_f4 w = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(At + off);
 #pragma unroll
-                for (int t = 0; t < MT; t++) af[t][ks] = to_agpr(__uint_as_float(__float_as_uint(v[t]) & kmask & mmask));
-                // 16 k-steps (16 loads, 64 registers) in flight at a time
-                if (ks % 16 == 15) __builtin_amdgcn_sched_barrier(0);
+                    for (int e = 0; e < 4; e++) v[e] = __uint_as_float(__float_as_uint(w[e]) & ok);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const unsigned ok = (k < K && c0 + e < M) ? 0xffffffffu : 0u;
+                        const unsigned off = ((unsigned)k * (unsigned)a.lda + (unsigned)(c0 + e)) & ok;
+                        v[e] = __uint_as_float(__float_as_uint(At[off]) & ok);
+                    }
+                }
+                dst[i] = v;
             }
-            return;
-        }
-        unsigned moff[MT], mmask[MT];
+        };
+        auto lstore = [&](const rs_f4 (&src)[NG]) {
 #pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const int m = mw + MT * l15 + t;
-            mmask[t] = m < M ? 0xffffffffu : 0u;
-            moff[t] = (unsigned)m & mmask[t];
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const int k = 4 * ks + kq;
-            const unsigned kmask = (ks < KS - RAG || k < K) ? 0xffffffffu : 0u;
-            const unsigned koff = ((unsigned)k & kmask) * (unsigned)a.lda;
-#pragma unroll
-            for (int t = 0; t < MT; t++) {
-                const float v = At[koff + moff[t]];
-                af[t][ks] = to_agpr(__uint_as_float(__float_as_uint(v) & kmask & mmask[t]));
+            for (int i = 0; i < NG; i++) {
+                const int idx = (int)threadIdx.x + NTH * ((i + rot) & (NG - 1));
+                *reinterpret_cast<rs_f4*>(&As[(idx >> 6) * LROW + (idx & 63) * 4]) = src[i];
             }
-            // 16 k-steps (64 loads) in flight at a time: unfenced, the scheduler issues all 256 loads at once and spills
-            if (ks % 16 == 15) __builtin_amdgcn_sched_barrier(0);
+        };
+        gload(0, g[0]);
+        if (PH > 1) gload(1, g[1]);
+#pragma unroll
+        for (int p = 0; p < PH; p++) {
+            lstore(g[p & 1]);
+            __syncthreads();
+            if (p + 2 < PH) gload(p + 2, g[p & 1]);
+            const float* fr = &As[kq * LROW + mw + MT * l15];
+#pragma unroll
+            for (int ksl = 0; ksl < 8; ksl++) {
+                if (MT == 4) {
+                    const rs_f4 v = *reinterpret_cast<const rs_f4*>(fr + 4 * ksl * LROW);
+#pragma unroll
+                    for (int t = 0; t < MT; t++) af[t][8 * p + ksl] = to_agpr(v[t]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < MT; t++) af[t][8 * p + ksl] = to_agpr(fr[4 * ksl * LROW + t]);
+                }
+            }
+            __syncthreads();
         }
     };
 

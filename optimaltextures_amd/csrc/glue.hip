@@ -145,6 +145,57 @@ __global__ __launch_bounds__(256) void glue_nhwc_kernel(GlueLArgs a) {
     *reinterpret_cast<float4*>(a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.C + c) = v;
 }
 
+// The same for C / 4 a power of two (every VGG width: 64 / 128 / 256 / 512 channels) — round 5: the kernel above moves ONE
+// 16-byte piece per thread behind an integer division (4 KB per block: 3.4-5.5 TB/s over the codec's tensors, the largest
+// HBM-bound class of a bench step).  Here a thread moves U pieces of U consecutive output ROWS at the same (pixel, channel
+// quad): the index arithmetic (a shift, the reflection of the column) is shared, U independent 16-byte loads are in
+// flight before the first store, and a block covers U rows.  grid (ceil(Wo * C/4 / 256), ceil(Ho / U), N)
+template <bool POOL, int U>
+__global__ __launch_bounds__(256) void glue_nhwc_rows_kernel(GlueLArgs a, int c4shift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ox = i >> c4shift;
+    if (ox >= a.Wo) return;
+    const int c = (i & ((1 << c4shift) - 1)) * 4;
+    const int n = blockIdx.z, oy0 = blockIdx.y * U;
+    const float4 b = a.bias ? *reinterpret_cast<const float4*>(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int mx = reflect_index(ox - a.pad, a.Wm);
+    if (!POOL && a.up) mx >>= 1;
+    const size_t row_in = (size_t)a.W * a.C;
+    const float* __restrict__ xin = a.x + (size_t)n * a.H * row_in + (size_t)(POOL ? 2 * mx : mx) * a.C + c;
+    const int dx = (POOL && 2 * mx + 1 < a.W) ? a.C : 0;   // ceil_mode partial windows
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int oy = oy0 + u < a.Ho ? oy0 + u : a.Ho - 1;   // (rows past the end re-read the last one: no divergent loads)
+        int my = reflect_index(oy - a.pad, a.Hm);
+        if (POOL) {
+            const int y0 = 2 * my, y1 = (y0 + 1 < a.H) ? y0 + 1 : y0;
+            const float4 p = *reinterpret_cast<const float4*>(xin + (size_t)y0 * row_in);
+            const float4 q = *reinterpret_cast<const float4*>(xin + (size_t)y0 * row_in + dx);
+            const float4 r = *reinterpret_cast<const float4*>(xin + (size_t)y1 * row_in);
+            const float4 t = *reinterpret_cast<const float4*>(xin + (size_t)y1 * row_in + dx);
+            v[u].x = fmaxf(fmaxf(p.x, q.x), fmaxf(r.x, t.x));
+            v[u].y = fmaxf(fmaxf(p.y, q.y), fmaxf(r.y, t.y));
+            v[u].z = fmaxf(fmaxf(p.z, q.z), fmaxf(r.z, t.z));
+            v[u].w = fmaxf(fmaxf(p.w, q.w), fmaxf(r.w, t.w));
+        } else {
+            if (a.up) my >>= 1;
+            v[u] = *reinterpret_cast<const float4*>(xin + (size_t)my * row_in);
+        }
+    }
+    float* __restrict__ o = a.out + (((size_t)n * a.Ho + oy0) * a.Wo + ox) * a.C + c;
+    const size_t row_out = (size_t)a.Wo * a.C;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        if (oy0 + u < a.Ho) {
+            float4 w = v[u];
+            w.x += b.x; w.y += b.y; w.z += b.z; w.w += b.w;
+            if (a.relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+            *reinterpret_cast<float4*>(o + (size_t)u * row_out) = w;
+        }
+    }
+}
+
 // mixed layouts: a 32 (pixels of one output row) x 32 (channels) tile per 256-thread block, transposed through LDS.
 // Reads run along the input's fastest dimension, writes along the output's.  grid (ceil(Wo/32) * ceil(C/32), Ho, N)
 template <bool IN_NHWC, bool POOL>
@@ -313,6 +364,16 @@ extern "C" int optex_vgg_glue_layout(const float* x, const float* bias, float* o
     const bool vec = in_nhwc && out_nhwc && C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
     if (vec) {
+        const int c4 = C / 4;
+        if ((c4 & (c4 - 1)) == 0 && a.Ho >= 8) {  // every VGG width; four rows per thread
+            int sh = 0;
+            while ((1 << sh) < c4) sh++;
+            constexpr int U = 4;
+            dim3 grid((unsigned)(((long long)a.Wo * c4 + 255) / 256), (unsigned)((a.Ho + U - 1) / U), (unsigned)N);
+            if (pool) hipLaunchKernelGGL((glue_nhwc_rows_kernel<true, U>), grid, dim3(256), 0, st, a, sh);
+            else hipLaunchKernelGGL((glue_nhwc_rows_kernel<false, U>), grid, dim3(256), 0, st, a, sh);
+            return check_launch("glue_nhwc_rows_kernel");
+        }
         dim3 grid((unsigned)(((long long)a.Wo * (C / 4) + 255) / 256), (unsigned)a.Ho, (unsigned)N);
         if (pool) hipLaunchKernelGGL(glue_nhwc_kernel<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(glue_nhwc_kernel<false>, grid, dim3(256), 0, st, a);

@@ -75,7 +75,12 @@ int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float
 int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                          int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
                          const float* tmn_parts, const float* tmx_parts, int parts, hipStream_t st,
-                         const float* smn_given = nullptr, const float* smx_given = nullptr, bool ws_clean = false);
+                         const float* smn_given = nullptr, const float* smx_given = nullptr, bool ws_clean = false,
+                         const unsigned* shist_given = nullptr);
+// shist_given [src_n_seg, C, 256]: the source columns' histograms over [smn_given, smx_given] (col_hist_launch), taken by every
+// column whose joint range is the source's own
+int col_hist_launch(const float* x, long ld, long ss, long n, int C, int n_seg, const float* lo, const float* hi, unsigned* hist,
+                    hipStream_t st);
 // clears the counters of a cdf scratch (its pipeline leaves them clear: once per loop); per-column min / max of segments
 int cdf_ws_clear(void* ws, int C, int n_seg, hipStream_t st);
 int col_minmax_launch(const float* x, long ld, long ss, long n, int C, int n_seg, float* mn, float* mx, hipStream_t st);

@@ -82,6 +82,7 @@ struct LoopWs {
     // loop (one batched GEMM, one min / max or one sort launch for all of them) — `ys` then holds iters rotated copies
     bool hoist = false;
     float *smn_all = nullptr, *smx_all = nullptr;   // cdf: style min / max per (iteration, style segment, channel)
+    unsigned* shist_all = nullptr;                  // cdf: style histograms over that range, [iters, Ss, C, 256]
     int* sort_flags = nullptr;                      // sort: scratch of the one style sort
 
     // Ss: segments of the ROTATED style the matcher sees (= n_seg when every segment has its own rotations: own_rot)
@@ -100,6 +101,7 @@ struct LoopWs {
             if (hoist && mode == MODE_CDF) {
                 smn_all = b.take<float>((size_t)iters * Ss * C);
                 smx_all = b.take<float>((size_t)iters * Ss * C);
+                shist_all = b.take<unsigned>((size_t)iters * Ss * C * kBins);
             }
             if (hoist && mode == MODE_SORT) sort_flags = b.take<int>((size_t)iters * Ss * C);
             if (!fused && rs_parts) {  // cdf: the joint range of histmatch.py:52-53; sort: the rank kernel's bucket range
@@ -511,9 +513,12 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
         if ((rc = optex_gemm_tn(R32, C, (long)C * C, style, ns, 0, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C,
                                 C, ns, iters, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
             return rc;
-        if (mode == MODE_CDF)
-            rc = col_minmax_launch(w.ys, ns, ss, ns, C, iters * rs_seg, w.smn_all, w.smx_all, st);
-        else
+        if (mode == MODE_CDF) {
+            // ... and its histogram over its own range: the joint range of histmatch.py:52-53 IS the style's range for every
+            // pastiche column the style's range contains, and then histc(style, 256, lo, hi) is the same for all textures
+            if ((rc = col_minmax_launch(w.ys, ns, ss, ns, C, iters * rs_seg, w.smn_all, w.smx_all, st))) return rc;
+            rc = col_hist_launch(w.ys, ns, ss, ns, C, iters * rs_seg, w.smn_all, w.smx_all, w.shist_all, st);
+        } else
             rc = sort_columns_inplace(w.ys, ns, iters * rs_seg * C, w.sort_flags, st);
         if (rc) return rc;
     }
@@ -540,7 +545,8 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
             rc = cdf_match_parts_impl(w.y, n, xs, n, ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, nullptr,
                                       mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, st,
                                       w.hoist ? w.smn_all + (size_t)it * rs_seg * C : nullptr,
-                                      w.hoist ? w.smx_all + (size_t)it * rs_seg * C : nullptr, true);
+                                      w.hoist ? w.smx_all + (size_t)it * rs_seg * C : nullptr, true,
+                                      w.hoist ? w.shist_all + (size_t)it * rs_seg * C * kBins : nullptr);
         else
             rc = sort_match_impl(w.y, n, xs, n, ys, ns, ss, ns, rs_seg, C, n_seg, w.y, n, xs, w.mode_ws, st,
                                  mm ? w.rs_a : nullptr, mm ? w.rs_b : nullptr, w.rs_parts, w.hoist ? ys : nullptr);

@@ -827,6 +827,29 @@ def test_ot_loop_at_the_small_batch_shapes_vs_oracle(dev, mode, n, ns):
             assert maxrel(got[s], w) <= 2 * LIN_TOL, f"{mode} n={n} segment {s}: {maxrel(got[s], w):.2e}"
 
 
+@pytest.mark.parametrize("S,C,n,ns,style_scale", [(4, 64, 4096, 3072, 6.0), (3, 256, 1024, 2048, 0.2), (2, 32, 4096, 4096, 2.0)])
+def test_ot_loop_cdf_shared_style_histogram_vs_oracle(dev, S, C, n, ns, style_scale):
+    """round 5: with a shared style and shared rotations the style's histogram over its OWN range is taken once per (iteration,
+    channel) and used by every texture whose joint range (histmatch.py:52-53) is the style's range; the others bin the style
+    with their own range as before.  A style much wider than the pastiche (every column reuses), much narrower (none does)
+    and alike (mixed): all bit-exact against the oracle chain, every segment."""
+    from optimaltextures_amd import ops
+    rng = np.random.default_rng(S * C + int(10 * style_scale))
+    x = relu_feat(rng, S, C, n, scale=2.0, shift=0.3)
+    sty = relu_feat(rng, 1, C, ns, scale=style_scale, shift=0.5)
+    lr = orc.LegacyRNG(C + S)
+    R = np.stack([orc.random_rotation(C, lr) for _ in range(3)]).astype(np.float32)
+    Rt = np.ascontiguousarray(R.transpose(0, 2, 1))
+    xd = cu(x, dev)
+    ops.ot_loop("cdf", xd, cu(sty, dev), cu(R, dev), cu(Rt, dev))
+    got = xd.cpu().numpy()
+    for s in range(S):
+        w = x[s]
+        for it in range(3):
+            w = orc.unrotate_cm(orc.cdf_match(orc.rotate_cm(w, R[it]), orc.rotate_cm(sty[0], R[it])), R[it])
+        assert biteq(got[s], w), f"segment {s}: {np.count_nonzero(got[s] != w)} elements differ"
+
+
 @pytest.mark.parametrize("mode,S,C,n,ns,blend", [("cdf", 3, 32, 1024, 768, False), ("sort", 2, 16, 576, 560, True),
                                                   ("cdf", 8, 256, 4096, 3072, False), ("cdf", 4, 181, 4096, 3072, True)])
 def test_per_texture_rotation_streams_equal_separate_runs(dev, mode, S, C, n, ns, blend):
