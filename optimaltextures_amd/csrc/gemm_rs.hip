@@ -228,8 +228,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
 
     rs_f4 br[RS_DEPTH];
 #pragma unroll
-    for (int d = 0; d < RS_DEPTH; d++) {
-        br[d] = rs_f4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < RS_DEPTH; d++) br[d] = rs_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < RS_DEPTH - 1; d++) {  // k-steps 0 .. DEPTH - 2; the loop requests k-step ks - 1 + DEPTH at k-step ks
         load_next(d, br[d]);
         load_sub(d, bsr[EXTRA == 2 ? d : 0]);
     }
@@ -257,11 +258,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
 #pragma unroll
                 for (int j = 0; j < 4; j++) b[j] = __uint_as_float(__float_as_uint(b[j]) & pm);
             }
-            // refill the slot: k-step ks + DEPTH of this tile, or the head of the next one
-            if (ks + RS_DEPTH == KS) pk = nbase;
+            // refill the slot of the PREVIOUS k-step — k-step ks - 1 + DEPTH of this tile, or the head of the next one.  One
+            // k-step late on purpose (round 5 timeline): a load whose destination registers were read by the MFMA issued just
+            // before it waits for that MFMA — one 32-cycle slot of the matrix pipe per k-step (2180 against 2076 cycles per
+            // 64 MFMAs); a k-step later the readers are long done.  DEPTH - 1 k-steps stay in flight.
+            if (ks - 1 + RS_DEPTH == KS) pk = nbase;
 #ifndef RS_PROBE_NOLOAD
-            load_next((ks + RS_DEPTH) % KS, br[ks % RS_DEPTH]);
-            load_sub((ks + RS_DEPTH) % KS, bsr[EXTRA == 2 ? ks % RS_DEPTH : 0]);
+            load_next((ks - 1 + RS_DEPTH) % KS, br[(ks - 1 + RS_DEPTH) % RS_DEPTH]);
+            load_sub((ks - 1 + RS_DEPTH) % KS, bsr[EXTRA == 2 ? (ks - 1 + RS_DEPTH) % RS_DEPTH : 0]);
 #endif
             if (ks < KS - RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
 #pragma unroll

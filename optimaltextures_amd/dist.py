@@ -64,9 +64,13 @@ class StyleSync:
 
     STATUS_WORDS = 64  # the mark travels in front of the payload; 64 floats keep every tensor on its 256-byte boundary
 
-    def __init__(self, device, src: int = 0, group=None, always: bool = False):
-        """always=True: issue the broadcasts even in a world of one (tests: the RCCL call sequence on one GPU)"""
+    def __init__(self, device, src: int = 0, group=None, always: bool = False, spread: bool = True):
+        """always=True: issue the broadcasts even in a world of one (tests: the RCCL call sequence on one GPU).
+        spread=True (default): when every shape is known in advance (no PCA) the driver lets rank (src + p) mod world encode
+        and send the style side of pass p — EVERY rank must then hold the real style images (bench.py and the CLI load them
+        on every rank); spread=False: everything comes from `src`, the other ranks' style images are never looked at."""
         self.device, self.src, self.group, self.always = torch.device(device), src, group, always
+        self.spread = bool(spread)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_moved = 0    # payload + header bytes this rank sent or received
@@ -97,19 +101,23 @@ class StyleSync:
     def header_len(n_tensors: int, n_ints: int) -> int:
         return 3 + n_tensors * (1 + MAX_DIMS) + n_ints
 
-    def broadcast_known(self, tensors: Optional[List[torch.Tensor]], shapes: List[Tuple[int, ...]]):
+    def broadcast_known(self, tensors: Optional[List[torch.Tensor]], shapes: List[Tuple[int, ...]], src: Optional[int] = None):
         """The exchange when every rank can compute every SHAPE in advance (no PCA: the rank k is the only data-dependent
         size): no header, no host synchronisation at all — ONE asynchronous payload broadcast; the receiving ranks keep
-        enqueueing kernels behind it.  source: list of fp32 tensors of exactly these shapes -> everyone: the tensors."""
+        enqueueing kernels behind it.  source: list of fp32 tensors of exactly these shapes -> everyone: the tensors.
+        src: the rank that holds the tensors of THIS exchange (default: the hook's source rank) — the driver spreads the style
+        sides of a call's passes over the ranks, one source each (OptimalTexture.prefetch_style_sides)."""
         if self.world == 1 and not self.always:
             return list(tensors)
+        src = self.src if src is None else int(src)
+        is_source = self.rank == src
         self.verify()
         numels = [int(torch.Size(sh).numel()) for sh in shapes]
         head = self.STATUS_WORDS
         total = head + sum(_padded(k) for k in numels)
         flat = torch.empty(total, dtype=torch.float32, device=self.device)
         bad = False
-        if self.is_source:
+        if is_source:
             bad = tensors is None or len(tensors) != len(shapes) or any(tuple(t.shape) != tuple(sh) or t.dtype != torch.float32
                                                                        for t, sh in zip(tensors or [], shapes))
             if bad:
@@ -122,7 +130,7 @@ class StyleSync:
                 for t, k in zip(tensors, numels):
                     flat[off:off + k].copy_(t.reshape(-1))
                     off += _padded(k)
-        work = dist.broadcast(flat, self.src, group=self.group, async_op=True)
+        work = dist.broadcast(flat, src, group=self.group, async_op=True)
         self.messages += 1
         self.bytes_moved += total * 4
         out, off = [], head
@@ -130,7 +138,7 @@ class StyleSync:
             out.append(flat[off:off + k].view(tuple(sh)))
             off += _padded(k)
         work.wait()  # RCCL: the current stream waits for the communicator's stream, the host does not block
-        if self.is_source and bad:
+        if is_source and bad:
             raise ValueError("StyleSync.broadcast_known: the source rank's tensors do not have the announced shapes")
         if flat.is_cuda:
             host = torch.empty(1, dtype=torch.float32, pin_memory=True)

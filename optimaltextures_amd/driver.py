@@ -420,45 +420,35 @@ class OptimalTexture(torch.nn.Module):
             if resized:
                 hw = (get_size(size, 1.0, content.shape[2], content.shape[3], oversize=True) if content is not None
                       else (size, size))
-        sides = None
-        if need:
-            computed = self._compute_style_sides([self._style_tensors(styles, size, resized) for size, resized in plan])
-            sides = [(resized,) + side for (size, resized), side in zip(plan, computed)]
         if self.style_sync is None or self.use_pca:
+            sides = None
+            if need:
+                computed = self._compute_style_sides([self._style_tensors(styles, size, resized) for size, resized in plan])
+                sides = [(resized,) + side for (size, resized), side in zip(plan, computed)]
             return self._sync_style_sides(sides, self.passes)
-        # shapes from the layer lists alone
-        shapes, hws = [], []
-        for size, resized in plan:
-            per_pass = []
+        # Shapes from the layer lists alone: every rank knows what every exchange carries, so the style sides of the passes are
+        # SPREAD over the ranks — pass p is encoded by rank p mod world and broadcast from there (round 5).  One rank encoding
+        # all of them sat on the critical path of every rank at the start of a call (five one-image encodes, 2-3 ms of a
+        # 47 ms step at 8 textures per GPU: BASELINE config 4); now no rank encodes more than ceil(passes / world) of them and
+        # they run side by side.  Every rank issues the same exchanges in the same order (pass 0 first: it is needed first).
+        sync = self.style_sync
+        out = []
+        for p, (size, resized) in enumerate(plan):
+            shapes, hws = [], []
             for encoder in self.encoders:
                 dims = [get_size(size, self.style_scale, st.shape[2], st.shape[3]) if resized else (int(st.shape[2]), int(st.shape[3]))
                         for st in styles]
                 c, h, w = encoder.out_shape(*dims[0])
                 assert all(encoder.out_shape(*d) == (c, h, w) for d in dims), "style images must have the same shape"
                 shapes.append((len(styles), c, h * w))
-                per_pass.append((h, w))
-            hws.append(per_pass)
-        flat = [f for side in sides for f in side[1]] if need else None
-        got = self.style_sync.broadcast_known(flat, shapes)
-        n_enc, out = len(self.encoders), []
-        for p, (size, resized) in enumerate(plan):
-            feats = got[p * n_enc:(p + 1) * n_enc]
-            out.append((resized, feats, [torch.empty((0, 0), device=f.device) for f in feats], hws[p]))
+                hws.append((h, w))
+            src = (sync.src + p) % sync.world if sync.spread else sync.src
+            flat = None
+            if sync.rank == src:
+                flat = self._compute_style_sides([self._style_tensors(styles, size, resized)])[0][0]
+            feats = sync.broadcast_known(flat, shapes, src=src)
+            out.append((resized, feats, [torch.empty((0, 0), device=f.device) for f in feats], hws))
         return out
-
-    def rotation_schedule(self, sides=None):
-        """[(C, iterations), ...] of a forward() call in the order the loops ask for their rotations (pass-major, encoder-
-        minor, the colour-transfer draw last).  Without PCA it follows from the layer lists alone; with PCA the kept ranks
-        are those of `sides` (prefetch_style_sides), which must then be given."""
-        schedule = []
-        for p in range(self.passes):
-            for li, encoder in enumerate(self.encoders):
-                enc_index = li if self.index_by_position else 5 - encoder.depth
-                c = int(sides[p][2][li].shape[1]) if self.use_pca else encoder.out_shape(16, 16)[0]
-                schedule.append((c, layer_iters(self.iters_per_pass_and_layer, p, enc_index)))
-        if self.color_transfer == "opt":
-            schedule.append((3, 3))
-        return schedule
 
     def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int,
                       style_side=None):

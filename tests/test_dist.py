@@ -201,18 +201,19 @@ def _oracle_backed_ops():
     ops.ot_loop = ot_loop
 
 
-def _bench_step_job(rank, world, device):
+def _bench_step_job(rank, world, device, spread=False):
     """what bench.py's step() does on every rank: B independent textures, relu-layer encode -> OT iterations -> decode over
-    the multi-resolution passes, the style side arriving from rank 0 through StyleSync (ranks != 0 hold a blank style)"""
+    the multi-resolution passes, the style side arriving through StyleSync — from rank 0 alone (spread=False: ranks != 0 hold a
+    blank style) or pass p from rank p mod world (spread=True, the default of bench.py and the CLI)"""
     from optimaltextures_amd.driver import OptimalTexture
     _oracle_backed_ops()
     tex = OptimalTexture(size=288, iters=20, passes=2, hist_mode="cdf", no_pca=True, layers=(1,), independent=True).eval()
     if world > 1:
-        tex.style_sync = otdist.StyleSync(device)
+        tex.style_sync = otdist.StyleSync(device, spread=spread)
     g = torch.Generator().manual_seed(77)
     style = torch.rand(1, 3, 64, 96, generator=g)
-    if world > 1 and rank != 0:
-        style = torch.zeros_like(style)          # only the source rank's style may matter
+    if world > 1 and rank != 0 and not spread:
+        style = torch.zeros_like(style)          # spread=False: only the source rank's style may matter
     # bench.py's seeding rule: this rank's step 0 is rotation group `rank` = textures 2 * rank, 2 * rank + 1
     tex.rng = otdist.rotation_rng(0, rank)
     pastiche = otdist.texture_noise(2 * rank, 2, (3, 288, 288), device, seed=0)
@@ -225,16 +226,20 @@ def _bench_step_job(rank, world, device):
 def test_bench_step_with_style_sync_gloo_world2():
     """Both ranks run the whole forward() with the packed style broadcast; rank 1 (blank local style) must produce exactly
     what a single process computes for rank 1's seeds with the real style: the broadcast delivered rank 0's style side for
-    every pass, and nothing else crossed ranks.  Without PCA every shape is known in advance: one exchange per forward
-    call = ONE message (the payload), no header and no host synchronisation."""
-    res = run_world(_bench_step_job, 2)
-    (out0, (msgs0, bytes0)), (out1, (msgs1, bytes1)) = res[0], res[1]
-    assert msgs0 == msgs1 == 1 and bytes0 == bytes1 > 0
-    assert out0.shape == out1.shape == (2, 3, 288, 288) and np.isfinite(out0).all() and np.isfinite(out1).all()
-    assert not np.array_equal(out0, out1)                      # different seeds per rank: different textures
-
+    every pass, and nothing else crossed ranks.  Without PCA every shape is known in advance: one header-free payload per
+    pass, no host synchronisation — all from rank 0, or (spread, the default) pass p from rank p mod 2."""
     ref = run_world(_single_rank1_job, 1)[0]
-    assert np.array_equal(out1, ref)
+    for job in (_bench_step_job, _bench_step_spread_job):
+        res = run_world(job, 2)
+        (out0, (msgs0, bytes0)), (out1, (msgs1, bytes1)) = res[0], res[1]
+        assert msgs0 == msgs1 == 2 and bytes0 == bytes1 > 0    # one payload per pass (two passes), nothing else
+        assert out0.shape == out1.shape == (2, 3, 288, 288) and np.isfinite(out0).all() and np.isfinite(out1).all()
+        assert not np.array_equal(out0, out1)                      # different seeds per rank: different textures
+        assert np.array_equal(out1, ref)
+
+
+def _bench_step_spread_job(rank, world, device):
+    return _bench_step_job(rank, world, device, spread=True)
 
 
 def _single_rank1_job(rank, world, device):
@@ -350,6 +355,28 @@ def _known_shapes_job(rank, world, device):
         raised = True
     again = sync.broadcast_known([torch.full((4,), 1.5)] if sync.is_source else None, [(4,)])
     return [t.numpy().copy() for t in got], sync.messages, raised, again[0].tolist()
+
+
+def _known_shapes_round_robin_job(rank, world, device):
+    """broadcast_known with a source per exchange (the driver spreads the style sides of a call's passes over the ranks):
+    exchange p comes from rank p mod world; every rank ends up with every payload, whoever computed it"""
+    sync = otdist.StyleSync(device)
+    got = []
+    for p in range(5):
+        src = p % world
+        g = torch.Generator().manual_seed(100 + p)
+        payload = [torch.rand(1, 4, 6 + p, generator=g)] if rank == src else None   # only the source holds the data
+        got.append(sync.broadcast_known(payload, [(1, 4, 6 + p)], src=src)[0].numpy().copy())
+    return got, sync.messages
+
+
+def test_style_sync_known_shapes_one_source_per_pass_gloo_world2():
+    res = run_world(_known_shapes_round_robin_job, 2)
+    (a, ma), (b, mb) = res[0], res[1]
+    assert ma == mb == 5
+    for p, (x, y) in enumerate(zip(a, b)):
+        want = torch.rand(1, 4, 6 + p, generator=torch.Generator().manual_seed(100 + p)).numpy()
+        assert np.array_equal(x, want) and np.array_equal(y, want)
 
 
 def test_style_sync_known_shapes_single_message_gloo_world2():

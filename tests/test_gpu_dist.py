@@ -103,7 +103,7 @@ with torch.inference_mode():
         tex.style_sync = otdist.StyleSync(dev, always=True)
         hooked = tex.forward(noise(), [style], None)
         drv.ot_iterations = real
-        assert tex.style_sync.messages == 1 and len(calls) == 5   # no PCA: shapes known everywhere, payload only
+        assert tex.style_sync.messages == 5 and len(calls) == 5   # no PCA: shapes known everywhere, one payload per pass (its source = pass mod world)
         assert hooked.shape == (8, 3, 512, 512) and bool(torch.isfinite(hooked).all())
         assert not bool((hooked[0] == hooked[1]).all())      # independent textures
         import numpy as np
