@@ -43,6 +43,7 @@
 // Optional per-row statistics of the output (GemmArgs::rowstat, 1 = min / max, 2 = sum) are taken from the accumulators:
 // one partial per 64-pixel tile, [n_seg][n / 64][M].
 #include "gemm_args.h"
+#include <type_traits>
 #include "timeline.h"
 
 namespace optex {
@@ -129,61 +130,85 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
     __shared__ __attribute__((aligned(16))) float As[32 * LROW];
     auto load_matrix = [&](int seg) {
         const rs_gfptr At = reinterpret_cast<rs_gfptr>(rs_uniform(a.At + (size_t)seg * a.at_ss));
-        const bool vec = a.a_vec && (M & 3) == 0;   // uniform: 16-byte global loads, a piece is all inside M or all outside
         const int rot = (int)(blockIdx.x + blockIdx.y) & (NG - 1);
-        rs_f4 g[2][NG];
-        auto gload = [&](int p, rs_f4 (&dst)[NG]) {
-#pragma unroll
-            for (int i = 0; i < NG; i++) {
+        // VECA (one uniform decision for the whole staging — taken per piece it put a branch and an s_waitcnt vmcnt(0) behind
+        // every single load: 64 dependent L2 round trips, 25-30 us): 16-byte global loads, a piece is all inside M or all outside
+        auto stage = [&](auto veca) {
+            constexpr bool VECA = decltype(veca)::value;
+            rs_f4 g[2][NG];
+            // piece i of block p: row 32 p + (idx >> 6), columns 4 (idx & 63) .. + 3; inside K x M?
+            auto where = [&](int p, int i, int& row, int& c0, int& k) {
                 const int idx = (int)threadIdx.x + NTH * ((i + rot) & (NG - 1));
-                const int row = idx >> 6, c0 = (idx & 63) * 4, k = 32 * p + row;
-                rs_f4 v = rs_f4{0.f, 0.f, 0.f, 0.f};
-                if (vec) {
-                    // (masks, not selects: see the header — a select of a loaded value becomes a branch around the load)
-                    const unsigned ok = (k < K && c0 < M) ? 0xffffffffu : 0u;
-                    const unsigned off = ((unsigned)k * (unsigned)a.lda + (unsigned)c0) & ok;
-                    const rs_f4 w = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(At + off);
+                row = idx >> 6;
+                c0 = (idx & 63) * 4;
+                k = 32 * p + row;
+            };
+            // the loads of a block go out back to back, RAW (clamped addresses); what lies beyond K / M is zeroed when the block
+            // is written to LDS — masked right behind its load, every piece waited for its own round trip (s_waitcnt vmcnt(0)
+            // 64 times over: the 25-30 us the first versions of this prologue took)
+            auto gload = [&](int p, rs_f4 (&dst)[NG]) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = __uint_as_float(__float_as_uint(w[e]) & ok);
-                } else {
+                for (int i = 0; i < NG; i++) {
+                    int row, c0, k;
+                    where(p, i, row, c0, k);
+                    if (VECA) {
+                        const unsigned ok = (k < K && c0 < M) ? 0xffffffffu : 0u;
+                        const unsigned off = ((unsigned)k * (unsigned)a.lda + (unsigned)c0) & ok;
+                        dst[i] = *reinterpret_cast<const __attribute__((address_space(1))) rs_f4*>(At + off);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const unsigned ok = (k < K && c0 + e < M) ? 0xffffffffu : 0u;
-                        const unsigned off = ((unsigned)k * (unsigned)a.lda + (unsigned)(c0 + e)) & ok;
-                        v[e] = __uint_as_float(__float_as_uint(At[off]) & ok);
+                        for (int e = 0; e < 4; e++) {
+                            const unsigned ok = (k < K && c0 + e < M) ? 0xffffffffu : 0u;
+                            dst[i][e] = At[((unsigned)k * (unsigned)a.lda + (unsigned)(c0 + e)) & ok];
+                        }
                     }
                 }
-                dst[i] = v;
-            }
-        };
-        auto lstore = [&](const rs_f4 (&src)[NG]) {
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto lstore = [&](int p, const rs_f4 (&src)[NG]) {
 #pragma unroll
-            for (int i = 0; i < NG; i++) {
-                const int idx = (int)threadIdx.x + NTH * ((i + rot) & (NG - 1));
-                *reinterpret_cast<rs_f4*>(&As[(idx >> 6) * LROW + (idx & 63) * 4]) = src[i];
-            }
-        };
-        gload(0, g[0]);
-        if (PH > 1) gload(1, g[1]);
+                for (int i = 0; i < NG; i++) {
+                    int row, c0, k;
+                    where(p, i, row, c0, k);
+                    rs_f4 v;
 #pragma unroll
-        for (int p = 0; p < PH; p++) {
-            lstore(g[p & 1]);
-            __syncthreads();
-            if (p + 2 < PH) gload(p + 2, g[p & 1]);
-            const float* fr = &As[kq * LROW + mw + MT * l15];
-#pragma unroll
-            for (int ksl = 0; ksl < 8; ksl++) {
-                if (MT == 4) {
-                    const rs_f4 v = *reinterpret_cast<const rs_f4*>(fr + 4 * ksl * LROW);
-#pragma unroll
-                    for (int t = 0; t < MT; t++) af[t][8 * p + ksl] = to_agpr(v[t]);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < MT; t++) af[t][8 * p + ksl] = to_agpr(fr[4 * ksl * LROW + t]);
+                    for (int e = 0; e < 4; e++) {
+                        const unsigned ok = (k < K && c0 + (VECA ? 0 : e) < M) ? 0xffffffffu : 0u;
+                        v[e] = __uint_as_float(__float_as_uint(src[i][e]) & ok);
+                    }
+                    *reinterpret_cast<rs_f4*>(&As[row * LROW + c0]) = v;
                 }
+            };
+            gload(0, g[0]);
+            if (PH > 1) gload(1, g[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < PH; p++) {
+                lstore(p, g[p & 1]);
+                __syncthreads();
+                if (p + 2 < PH) gload(p + 2, g[p & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // the loads of two blocks ahead are on their way before this block is unpacked
+                const float* fr = &As[kq * LROW + mw + MT * l15];
+                rs_f4 fv[8];   // the block's eight fragment reads in flight together, then into the accumulation registers
+#pragma unroll
+                for (int ksl = 0; ksl < 8; ksl++) {
+                    if (MT == 4) {
+                        fv[ksl] = *reinterpret_cast<const rs_f4*>(fr + 4 * ksl * LROW);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < MT; t++) fv[ksl][t] = fr[4 * ksl * LROW + t];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ksl = 0; ksl < 8; ksl++)
+#pragma unroll
+                    for (int t = 0; t < MT; t++) af[t][8 * p + ksl] = to_agpr(fv[ksl][t]);
+                __syncthreads();
             }
-            __syncthreads();
-        }
+        };
+        if (a.a_vec && (M & 3) == 0) stage(std::true_type{});
+        else stage(std::false_type{});
     };
 
     // B addressing: ONE uniform running byte pointer (advanced by four rows per k-step and re-based at tile boundaries)

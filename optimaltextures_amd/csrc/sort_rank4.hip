@@ -160,8 +160,11 @@ __device__ __forceinline__ void r4_count4(uint32_t& lt, uint32_t& le, const uint
 // (15-24 % of a column's time in round 4's phase log, the wavefronts waiting on HBM with nothing to do) disappears from the
 // chain.  The key registers carry over the loop; the sorted source is staged without the register prefetch the one-column
 // kernel affords (those 16 registers are the next column's keys now).
+// (PERSIST runs with a 128-register budget — four waves per SIMD, ONE 1024-thread workgroup per CU: at 64 registers the carried
+// keys spilled, 154-308 VGPRs in scratch, and the kernel ran at half the speed of the one-column kernel:
+// profiles/r05_sort_persistent.md)
 template <int ITEMS, bool VEC, int NT, bool FULL, int MODE = SORT_MATCH, bool PERSIST = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match4_kernel(SortArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PERSIST ? 4 : 8, PERSIST ? 4 : 8))) void rank_match4_kernel(SortArgs a) {
     using K = R4<ITEMS, NT>;
     constexpr int NW = NT / 64;
     constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, QCAP = K::QCAP,
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
     const unsigned ns = MODE == SORT_MATCH ? (unsigned)a.ns : 1u;
     const int n = FULL ? CAP : (int)a.n;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tid = threadIdx.x, lane = tid & 63;   // (not const: the persistent loop makes them opaque once per column, see column())
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // VEC: the first 4 * Q registers are Q 16-byte loads (4 neighbouring pixels in one thread), the remaining T = ITEMS % 4
     // registers are scalar rows behind them (row r starts at pixel r * NT either way)
     constexpr int Q = VEC ? ITEMS / 4 : 0, T = ITEMS - 4 * Q;
@@ -237,6 +241,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (PERSIST && nxt >= 0 && !requested) load_keys(nxt);
         requested = true;
     };
+    if (PERSIST) {
+        // nothing derived from the thread index is loop-invariant for the compiler: hoisted out of the column loop, the element
+        // offsets, LDS addresses and validity masks of all phases stay live for the whole kernel — in scratch (64-VGPR budget)
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+    }
     SORT_PROBE(0);
     for (int i = tid; i < K::CNTW; i += NT) cnt[i] = 0u;
     if (tid < RK_COARSE) c1[tid] = 0u;
@@ -846,6 +856,45 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if ((r & 3) == 3) asm volatile("" ::: "memory");
         }
     };
+    if (PERSIST && VEC && a.out_vec && stage) {
+        // persistent kernel: the next column's keys occupy 16 registers by now — pick and store quad by quad (four values
+        // live at a time instead of sixteen)
+        auto pick_store = [&](auto same) {
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                float v4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = 4 * q + k;
+                    const unsigned rk = ragged(r) ? (valid(r) ? ba[r] : 0u) : ba[r];
+                    unsigned qi = rk;
+                    if (!decltype(same)::value) {
+                        const double aa = (double)(2u * rk + 1u) * (double)ns;
+                        qi = (unsigned)__builtin_fma(aa, a.inv_2nt, 7.450580596923828e-09);  // quantile_index (sort_common.h)
+                    }
+                    v4[k] = R4_LDS(const float, SLOT_B + (qi << 2));
+                }
+                const int e0 = (q * NT + tid9) * 4;
+                if (!ragged(4 * q) || e0 < n) *reinterpret_cast<float4*>(o + e0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int r = 4 * Q; r < ITEMS; r++) {
+                const unsigned rk = ragged(r) ? (valid(r) ? ba[r] : 0u) : ba[r];
+                unsigned qi = rk;
+                if (!decltype(same)::value) {
+                    const double aa = (double)(2u * rk + 1u) * (double)ns;
+                    qi = (unsigned)__builtin_fma(aa, a.inv_2nt, 7.450580596923828e-09);
+                }
+                const float vv = R4_LDS(const float, SLOT_B + (qi << 2));
+                if (valid(r)) o[r * NT + tid9] = vv;
+            }
+        };
+        if (ns == (unsigned)n) pick_store(std::true_type{});
+        else pick_store(std::false_type{});
+        SORT_PROBE(10);
+        return;
+    }
     if (stage) {
         if (ns == (unsigned)n) pick(std::true_type{}, std::true_type{});
         else pick(std::true_type{}, std::false_type{});
@@ -921,7 +970,7 @@ static int launch_rank4_items(SortArgs a, int ncols, hipStream_t st) {
     if constexpr (MODE == SORT_MATCH && NT >= 512 && CANVEC) {
         // the match of a batch: persistent workgroups, as many as are resident on the chip (2048 threads and 160 KiB of LDS
         // per CU), each walking its share of the columns with the next column's keys requested behind the rank step
-        const int per_cu_t = 2048 / NT, per_cu_l = (int)(163840 / lds);
+        const int per_cu_t = 1024 / NT, per_cu_l = (int)(163840 / lds);   // 128 registers per thread: 1024 threads per CU
         const long resident = (long)(per_cu_t < per_cu_l ? per_cu_t : per_cu_l) * device_cu_count();
         if (sort_rank4_persist && in_vec && resident > 0 && ncols > resident) {
             if (full) {
