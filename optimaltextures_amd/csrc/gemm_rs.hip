@@ -64,6 +64,9 @@ constexpr int RS_BN = 64;     // pixels per tile (4 sub-tiles of 16)
 #define RS_DEPTH_VALUE 16
 #endif
 constexpr int RS_DEPTH = RS_DEPTH_VALUE;   // k-steps of B in flight per wave (scripts/gemm_rs_probe.hip builds variants)
+#ifndef RS_SPLIT_LOAD
+#define RS_SPLIT_LOAD 1
+#endif
 constexpr int RS_RAG = 16;    // the last RS_RAG k-steps of an instantiation may lie (partly) beyond K
 
 struct RsArgs {
@@ -239,6 +242,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
         pk += step_bytes;
     };
 
+    // the same k-step in two 8-byte halves (KFULL loop only): a 16-byte-per-lane load is 1 KB per wave-instruction and holds the
+    // wave's issue for about two MFMA slots — the next MFMA goes out ~30 cycles late, once per k-step (round 5 timeline:
+    // 2196 cycles per 64 MFMAs against 2076 without the in-loop loads, whatever the placement of the load); two 512-byte
+    // pieces, each behind another group of MFMAs, fit into the 32-cycle shadows
+    typedef float rs_f2 __attribute__((ext_vector_type(2)));
+    auto load_half = [&](rs_f4& dst, int h) {
+        const rs_f2 v = *reinterpret_cast<const __attribute__((address_space(1))) rs_f2*>(pk + lane_off + 8u * (unsigned)h);
+        dst[2 * h] = v[0];
+        dst[2 * h + 1] = v[1];
+        if (h == 1) pk += step_bytes;
+    };
+
     // EXTRA == 2: the centring value bsub[4 ks + q] of every k-step travels through the ring beside its fragment (one more
     // dword load per k-step, L1 / L2 resident; KS registers of it kept for the whole launch spill).  The launcher keeps a
     // workgroup inside one segment when bsub varies with the segment.
@@ -288,13 +303,25 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
             // before it waits for that MFMA — one 32-cycle slot of the matrix pipe per k-step (2180 against 2076 cycles per
             // 64 MFMAs); a k-step later the readers are long done.  DEPTH - 1 k-steps stay in flight.
             if (ks - 1 + RS_DEPTH == KS) pk = nbase;
+            constexpr bool SPLIT = KFULL && EXTRA != 2 && RS_SPLIT_LOAD != 0 && MT >= 2;
 #ifndef RS_PROBE_NOLOAD
-            load_next((ks - 1 + RS_DEPTH) % KS, br[(ks - 1 + RS_DEPTH) % RS_DEPTH]);
-            load_sub((ks - 1 + RS_DEPTH) % KS, bsr[EXTRA == 2 ? (ks - 1 + RS_DEPTH) % RS_DEPTH : 0]);
+            if (SPLIT) {
+                load_half(br[(ks - 1 + RS_DEPTH) % RS_DEPTH], 0);
+            } else {
+                load_next((ks - 1 + RS_DEPTH) % KS, br[(ks - 1 + RS_DEPTH) % RS_DEPTH]);
+                load_sub((ks - 1 + RS_DEPTH) % KS, bsr[EXTRA == 2 ? (ks - 1 + RS_DEPTH) % RS_DEPTH : 0]);
+            }
 #endif
             if (ks < KS - RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
 #pragma unroll
                 for (int t = 0; t < MT; t++) {
+#ifndef RS_PROBE_NOLOAD
+                    if (SPLIT && t == MT / 2) {  // the second half of the refill, half a k-step later
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_half(br[(ks - 1 + RS_DEPTH) % RS_DEPTH], 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const rs_f4 c = ks == 0 ? rs_f4{0.f, 0.f, 0.f, 0.f} : acc[t][j];

@@ -163,8 +163,9 @@ __device__ __forceinline__ void r4_count4(uint32_t& lt, uint32_t& le, const uint
 // (PERSIST runs with a 128-register budget — four waves per SIMD, ONE 1024-thread workgroup per CU: at 64 registers the carried
 // keys spilled, 154-308 VGPRs in scratch, and the kernel ran at half the speed of the one-column kernel:
 // profiles/r05_sort_persistent.md)
-template <int ITEMS, bool VEC, int NT, bool FULL, int MODE = SORT_MATCH, bool PERSIST = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PERSIST ? 4 : 8, PERSIST ? 4 : 8))) void rank_match4_kernel(SortArgs a) {
+// WPE: waves per SIMD the kernel is compiled for (8 = 64 registers, 4 = 128)
+template <int ITEMS, bool VEC, int NT, bool FULL, int MODE = SORT_MATCH, bool PERSIST = false, int WPE = (PERSIST ? 4 : 8)>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rank_match4_kernel(SortArgs a) {
     using K = R4<ITEMS, NT>;
     constexpr int NW = NT / 64;
     constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, QCAP = K::QCAP,
@@ -935,8 +936,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PERSIST ? 4 
 }
 
 int device_cu_count();
-// (internal, not ABI: scripts/sort_time_probe.hip times the one-column-per-workgroup kernel against the persistent one)
+// (internal, not ABI: scripts/sort_time_probe.hip times the variants against each other)
 bool sort_rank4_persist = true;
+// 2: columns of more than 10240 keys on 512 threads x up to 32 keys at a 128-register budget — two workgroups (two columns) per
+// CU like the 1024-thread kernel, half the wavefronts, twice the work per wavefront
+int sort_rank4_wide = 0;
 
 template <typename KernT>
 static int launch_one4(KernT kern, DeviceOnce& once, size_t lds, const SortArgs& a, int ncols, int nt, hipStream_t st) {
@@ -1001,6 +1005,19 @@ static int launch_rank4_items(SortArgs a, int ncols, hipStream_t st) {
     return check_launch("rank_match4_kernel");
 }
 
+// experiment: ITEMS keys per thread on 512 threads, 128 registers (full, 16-byte aligned columns only)
+template <int ITEMS, int MODE>
+static int launch_rank4_wide(SortArgs a, int ncols, hipStream_t st) {
+    constexpr int NT = 512;
+    a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
+    const bool in_vec = a.n % 4 == 0 && a.ld % 4 == 0 && a.ss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
+    if (!in_vec || a.n != (long)ITEMS * NT) return launch_rank4_items<16, 1024, MODE>(a, ncols, st);
+    static DeviceOnce once;
+    int rc = launch_one4(rank_match4_kernel<ITEMS, true, NT, true, MODE, false, 4>, once, R4<ITEMS, NT>::LDS, a, ncols, NT, st);
+    if (rc) return rc;
+    return check_launch("rank_match4_kernel (512 x 32)");
+}
+
 template <int MODE>
 static int launch_rank4_mode(const SortArgs& a0, int ncols, hipStream_t st) {
     SortArgs a = a0;
@@ -1029,6 +1046,9 @@ static int launch_rank4_mode(const SortArgs& a0, int ncols, hipStream_t st) {
     // and slower: 9216 keys on 576 x 16, three workgroups of nine wavefronts to a CU, 822 us against 573 us on 1024 x 9;
     // 12544 keys on 896 x 14, 936 us against 826 us on 1024 x 13.)
     if (n == 10 * 640) return launch_rank4_items<10, 640, MODE>(a, ncols, st);
+    if constexpr (MODE == SORT_MATCH) {
+        if (sort_rank4_wide == 2 && n == 16384) return launch_rank4_wide<32, MODE>(a, ncols, st);
+    }
     switch ((int)((n + 1023) / 1024)) {
         case 6: return launch_rank4_items<6, 1024, MODE>(a, ncols, st);
         case 7: return launch_rank4_items<7, 1024, MODE>(a, ncols, st);
