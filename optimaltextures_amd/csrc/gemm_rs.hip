@@ -64,8 +64,19 @@ constexpr int RS_BN = 64;     // pixels per tile (4 sub-tiles of 16)
 #define RS_DEPTH_VALUE 16
 #endif
 constexpr int RS_DEPTH = RS_DEPTH_VALUE;   // k-steps of B in flight per wave (scripts/gemm_rs_probe.hip builds variants)
+#ifndef RS_DEPTH_DB_VALUE
+#define RS_DEPTH_DB_VALUE 8
+#endif
+constexpr int RS_DEPTH_DB = RS_DEPTH_DB_VALUE;
+#ifndef RS_FLUSH0
+#define RS_FLUSH0 8    // first k-step behind which a row tile of the previous pixel tile is stored (DB kernels) ...
+#define RS_FLUSHD 8    // ... and the distance to the next one
+#endif
+#ifndef RS_DB
+#define RS_DB 1        // 0: probe build without the double-buffered accumulators
+#endif
 #ifndef RS_SPLIT_LOAD
-#define RS_SPLIT_LOAD 1
+#define RS_SPLIT_LOAD 0   // in-loop refill as two 8-byte halves: measured SLOWER (111.6 against 115.1 TFLOP/s, profiles/r05_gemm_probes.md)
 #endif
 constexpr int RS_RAG = 16;    // the last RS_RAG k-steps of an instantiation may lie (partly) beyond K
 
@@ -86,9 +97,13 @@ struct RsArgs {
 #endif
 // KFULL: K == 4 KS exactly (the launcher checks): no k-step is ragged, so the masks, selects and uniform branches of the last
 // RS_RAG k-steps disappear and the whole k-loop is one basic block (C = 256 and C = 128, the un-projected hot shapes)
-template <int MT, int KS, int ROWSTAT, int EXTRA, int WPE = 1, bool KFULL = false>
+// DB: double-buffered accumulators — the previous tile's results leave during this tile's k-loop (run_tile / epilogue_row)
+template <int MT, int KS, int ROWSTAT, int EXTRA, int WPE = 1, bool KFULL = false, bool DB = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amdgpu_waves_per_eu(WPE, WPE))) void gemm_rs_kernel(RsArgs ra) {
-    static_assert(KS % RS_DEPTH == 0, "the B ring keeps its phase across tiles");
+    // B ring: DEPTH k-steps; the double-buffered kernels take RS_DEPTH_DB (their second accumulator set needs the registers:
+    // with 16 k-steps the hot loop spilled; 7 k-steps = 3800 cycles of lead against ~900 cycles of HBM latency)
+    constexpr int DEPTH = DB ? RS_DEPTH_DB : RS_DEPTH;
+    static_assert(KS % DEPTH == 0, "the B ring keeps its phase across tiles");
     constexpr int RAG = KFULL ? 0 : RS_RAG;   // the last RAG k-steps may lie (partly) beyond K
     const GemmArgs& a = ra.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -242,10 +257,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
         pk += step_bytes;
     };
 
-    // the same k-step in two 8-byte halves (KFULL loop only): a 16-byte-per-lane load is 1 KB per wave-instruction and holds the
-    // wave's issue for about two MFMA slots — the next MFMA goes out ~30 cycles late, once per k-step (round 5 timeline:
-    // 2196 cycles per 64 MFMAs against 2076 without the in-loop loads, whatever the placement of the load); two 512-byte
-    // pieces, each behind another group of MFMAs, fit into the 32-cycle shadows
+    // the same k-step in two 8-byte halves (-DRS_SPLIT_LOAD=1 probe build, KFULL loop only).  With its loads a k-step takes ~30
+    // cycles more than without (round 5 timeline: 2196 cycles per 64 MFMAs against 2076, wherever the load is placed);
+    // the guess that a 1 KB wave-instruction overruns its 32-cycle MFMA shadow and two 512-byte pieces would not was WRONG:
+    // two instructions cost more than one (2244 cycles per 64 MFMAs) — the cost is per VMEM instruction, not per byte
     typedef float rs_f2 __attribute__((ext_vector_type(2)));
     auto load_half = [&](rs_f4& dst, int h) {
         const rs_f2 v = *reinterpret_cast<const __attribute__((address_space(1))) rs_f2*>(pk + lane_off + 8u * (unsigned)h);
@@ -258,7 +273,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
     // dword load per k-step, L1 / L2 resident; KS registers of it kept for the whole launch spill).  The launcher keeps a
     // workgroup inside one segment when bsub varies with the segment.
     const rs_gfptr sub = EXTRA == 2 ? reinterpret_cast<rs_gfptr>(rs_uniform(a.bsub + (size_t)seg * a.bsub_ss)) : nullptr;
-    float bsr[EXTRA == 2 ? RS_DEPTH : 1];
+    float bsr[EXTRA == 2 ? DEPTH : 1];
     auto load_sub = [&](int ks, float& dst) {
         if (EXTRA == 2) {
             const int k = 4 * ks + kq;
@@ -266,11 +281,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
         }
     };
 
-    rs_f4 br[RS_DEPTH];
+    rs_f4 br[DEPTH];
 #pragma unroll
-    for (int d = 0; d < RS_DEPTH; d++) br[d] = rs_f4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < DEPTH; d++) br[d] = rs_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int d = 0; d < RS_DEPTH - 1; d++) {  // k-steps 0 .. DEPTH - 2; the loop requests k-step ks - 1 + DEPTH at k-step ks
+    for (int d = 0; d < DEPTH - 1; d++) {  // k-steps 0 .. DEPTH - 2; the loop requests k-step ks - 1 + DEPTH at k-step ks
         load_next(d, br[d]);
         load_sub(d, bsr[EXTRA == 2 ? d : 0]);
     }
@@ -279,73 +294,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
     load_matrix(seg);
     TL_STAMP(tl);
 
-    for (long tile = tb; tile < te; tile++) {
-        TL_STAMP(tl);
-        int nseg = seg, npt = pt;
-        if (tile + 1 < te) {  // (the last tile prefetches itself once more: in bounds, unused)
-            npt = pt + 1;
-            if (npt == ra.tiles_n) { npt = 0; nseg = seg + 1; }
-        }
-        const rs_gptr nbase = tile_base(nseg, npt);
-
-        rs_f4 acc[MT][4];
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            rs_f4 b = br[ks % RS_DEPTH];
-            if (EXTRA == 2) b = b - bsr[EXTRA == 2 ? ks % RS_DEPTH : 0];
-            if (ks >= KS - RAG) {  // the k-step that K cuts: its rows beyond K enter as exact zeros
-                const unsigned pm = (4 * ks + 4 > K && !ok_p) ? 0u : 0xffffffffu;
-#pragma unroll
-                for (int j = 0; j < 4; j++) b[j] = __uint_as_float(__float_as_uint(b[j]) & pm);
-            }
-            // refill the slot of the PREVIOUS k-step — k-step ks - 1 + DEPTH of this tile, or the head of the next one.  One
-            // k-step late on purpose (round 5 timeline): a load whose destination registers were read by the MFMA issued just
-            // before it waits for that MFMA — one 32-cycle slot of the matrix pipe per k-step (2180 against 2076 cycles per
-            // 64 MFMAs); a k-step later the readers are long done.  DEPTH - 1 k-steps stay in flight.
-            if (ks - 1 + RS_DEPTH == KS) pk = nbase;
-            constexpr bool SPLIT = KFULL && EXTRA != 2 && RS_SPLIT_LOAD != 0 && MT >= 2;
-#ifndef RS_PROBE_NOLOAD
-            if (SPLIT) {
-                load_half(br[(ks - 1 + RS_DEPTH) % RS_DEPTH], 0);
-            } else {
-                load_next((ks - 1 + RS_DEPTH) % KS, br[(ks - 1 + RS_DEPTH) % RS_DEPTH]);
-                load_sub((ks - 1 + RS_DEPTH) % KS, bsr[EXTRA == 2 ? (ks - 1 + RS_DEPTH) % RS_DEPTH : 0]);
-            }
-#endif
-            if (ks < KS - RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
-#pragma unroll
-                for (int t = 0; t < MT; t++) {
-#ifndef RS_PROBE_NOLOAD
-                    if (SPLIT && t == MT / 2) {  // the second half of the refill, half a k-step later
-                        __builtin_amdgcn_sched_barrier(0);
-                        load_half(br[(ks - 1 + RS_DEPTH) % RS_DEPTH], 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const rs_f4 c = ks == 0 ? rs_f4{0.f, 0.f, 0.f, 0.f} : acc[t][j];
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], af[t][ks], c, 0, 0, 0);
-                    }
-                }
-            }
-            // pin the software pipeline: unfenced, the machine scheduler sinks every load down to its consumer, eight
-            // k-steps later, and the loop becomes load -> s_waitcnt vmcnt(0) -> 16 MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef OPTEX_TIMELINE
-            if (ks % 4 == 3) {
-                tl_stamp(tl);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
-        }
-
-        // ---- epilogue.  acc[t][j][r] = OUT[m = mw + MT l15 + t][pixel p0 + 16 kq + 4 r + j]
-        float* __restrict__ Op = a.O + (size_t)seg * a.o_ss + (size_t)pt * RS_BN + 16 * kq;
-        const float* __restrict__ Cp = (EXTRA && a.content) ? a.content + (size_t)seg * a.o_ss + (size_t)pt * RS_BN + 16 * kq : nullptr;
-        const float* __restrict__ badd = (EXTRA && a.badd) ? a.badd + (size_t)seg * a.badd_ss : nullptr;
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
+    // One output row tile (t) of a finished pixel tile (eseg, ept): the lane's 16 consecutive pixels of channel m as four 16-byte
+    // stores, bias / blend (EXTRA), row statistics (ROWSTAT).  acc[t][j][r] = OUT[m = mw + MT l15 + t][pixel p0 + 16 kq + 4 r + j]
+    auto epilogue_row = [&](rs_f4 (&acc)[MT][4], int t, int eseg, int ept) {
+        float* __restrict__ Op = a.O + (size_t)eseg * a.o_ss + (size_t)ept * RS_BN + 16 * kq;
+        const float* __restrict__ Cp = (EXTRA && a.content) ? a.content + (size_t)eseg * a.o_ss + (size_t)ept * RS_BN + 16 * kq : nullptr;
+        const float* __restrict__ badd = (EXTRA && a.badd) ? a.badd + (size_t)eseg * a.badd_ss : nullptr;
+        const int seg = eseg, pt = ept;
+        (void)seg; (void)pt;
             const int m = mw + MT * l15 + t;
             const bool ok = m < M;
             const size_t row = (size_t)(ok ? m : 0) * a.ldo;
@@ -406,13 +362,130 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
                     if (kq == 0 && ok) a.rs_a[pidx] = sm;
                 }
             }
-        }
-        seg = nseg;
-        pt = npt;
-#ifdef OPTEX_TIMELINE
-        __builtin_amdgcn_sched_barrier(0);
-        tl_stamp(tl);
+    };
+    // the k-loop of one pixel tile into `acc`.  FLUSH (double-buffered accumulators, round 5): row tile t of the PREVIOUS pixel
+    // tile (`old`, finished at (oseg, opt)) is stored behind k-step RS_FLUSH0 + RS_FLUSHD t of this one — the 64 KB a
+    // workgroup writes per tile leave while the matrix pipe works instead of in a burst between two tiles (the epilogue was
+    // 3-6 % of a tile at 64 textures per step and 14-19 % at 8, where all CUs finish their few tiles in lockstep and the
+    // stores of the whole chip collide: profiles/r05_gemm_timeline.md)
+    auto run_tile = [&](rs_f4 (&acc)[MT][4], rs_f4 (&old)[MT][4], auto flush, int oseg, int opt, const rs_gptr nbase) {
+        constexpr bool FLUSH = decltype(flush)::value;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            rs_f4 b = br[ks % DEPTH];
+            if (EXTRA == 2) b = b - bsr[EXTRA == 2 ? ks % DEPTH : 0];
+            if (ks >= KS - RAG) {  // the k-step that K cuts: its rows beyond K enter as exact zeros
+                const unsigned pm = (4 * ks + 4 > K && !ok_p) ? 0u : 0xffffffffu;
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = __uint_as_float(__float_as_uint(b[j]) & pm);
+            }
+            // refill the slot of the PREVIOUS k-step — k-step ks - 1 + DEPTH of this tile, or the head of the next one.  One
+            // k-step late on purpose (round 5 timeline): a load whose destination registers were read by the MFMA issued just
+            // before it waits for that MFMA — one 32-cycle slot of the matrix pipe per k-step (2180 against 2076 cycles per
+            // 64 MFMAs); a k-step later the readers are long done.  DEPTH - 1 k-steps stay in flight.
+            if (ks - 1 + DEPTH == KS) pk = nbase;
+            constexpr bool SPLIT = KFULL && EXTRA != 2 && RS_SPLIT_LOAD != 0 && MT >= 2;
+#ifndef RS_PROBE_NOLOAD
+            if (SPLIT) {
+                load_half(br[(ks - 1 + DEPTH) % DEPTH], 0);
+            } else {
+                load_next((ks - 1 + DEPTH) % KS, br[(ks - 1 + DEPTH) % DEPTH]);
+                load_sub((ks - 1 + DEPTH) % KS, bsr[EXTRA == 2 ? (ks - 1 + DEPTH) % DEPTH : 0]);
+            }
 #endif
+            if (ks < KS - RAG || 4 * ks < K) {  // uniform: a k-step entirely beyond K does nothing
+#pragma unroll
+                for (int t = 0; t < MT; t++) {
+#ifndef RS_PROBE_NOLOAD
+                    if (SPLIT && t == MT / 2) {  // the second half of the refill, half a k-step later
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_half(br[(ks - 1 + DEPTH) % DEPTH], 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const rs_f4 c = ks == 0 ? rs_f4{0.f, 0.f, 0.f, 0.f} : acc[t][j];
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], af[t][ks], c, 0, 0, 0);
+                    }
+                }
+            }
+            // pin the software pipeline: unfenced, the machine scheduler sinks every load down to its consumer, eight
+            // k-steps later, and the loop becomes load -> s_waitcnt vmcnt(0) -> 16 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            if (FLUSH && ks >= RS_FLUSH0 && (ks - RS_FLUSH0) % RS_FLUSHD == 0 && (ks - RS_FLUSH0) / RS_FLUSHD < MT) {
+                epilogue_row(old, (ks - RS_FLUSH0) / RS_FLUSHD, oseg, opt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef OPTEX_TIMELINE
+            if (ks % 4 == 3) {
+                tl_stamp(tl);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        }
+
+    };
+
+    auto next_of = [&](long tile, int& nseg, int& npt) {
+        nseg = seg;
+        npt = pt;
+        if (tile + 1 < te) {  // (the last tile prefetches itself once more: in bounds, unused)
+            npt = pt + 1;
+            if (npt == ra.tiles_n) { npt = 0; nseg = seg + 1; }
+        }
+    };
+    if constexpr (DB) {
+        rs_f4 accA[MT][4], accB[MT][4];
+        int oseg = seg, opt = pt, nseg, npt;
+        long tile = tb;
+        TL_STAMP(tl);
+        next_of(tile, nseg, npt);
+        run_tile(accA, accB, std::false_type{}, 0, 0, tile_base(nseg, npt));   // the first tile has nothing to flush
+        for (;;) {
+            oseg = seg; opt = pt; seg = nseg; pt = npt;
+#ifdef OPTEX_TIMELINE
+            __builtin_amdgcn_sched_barrier(0);
+            tl_stamp(tl);
+#endif
+            if (++tile >= te) {
+#pragma unroll
+                for (int t = 0; t < MT; t++) epilogue_row(accA, t, oseg, opt);
+                break;
+            }
+            TL_STAMP(tl);
+            next_of(tile, nseg, npt);
+            run_tile(accB, accA, std::true_type{}, oseg, opt, tile_base(nseg, npt));
+            oseg = seg; opt = pt; seg = nseg; pt = npt;
+#ifdef OPTEX_TIMELINE
+            __builtin_amdgcn_sched_barrier(0);
+            tl_stamp(tl);
+#endif
+            if (++tile >= te) {
+#pragma unroll
+                for (int t = 0; t < MT; t++) epilogue_row(accB, t, oseg, opt);
+                break;
+            }
+            TL_STAMP(tl);
+            next_of(tile, nseg, npt);
+            run_tile(accA, accB, std::true_type{}, oseg, opt, tile_base(nseg, npt));
+        }
+    } else {
+        for (long tile = tb; tile < te; tile++) {
+            TL_STAMP(tl);
+            int nseg, npt;
+            next_of(tile, nseg, npt);
+            rs_f4 acc[MT][4];
+            run_tile(acc, acc, std::false_type{}, 0, 0, tile_base(nseg, npt));
+#pragma unroll
+            for (int t = 0; t < MT; t++) epilogue_row(acc, t, seg, pt);
+            seg = nseg;
+            pt = npt;
+#ifdef OPTEX_TIMELINE
+            __builtin_amdgcn_sched_barrier(0);
+            tl_stamp(tl);
+#endif
+        }
     }
 #ifdef OPTEX_TIMELINE
     tl_stamp_real(tl);
@@ -446,7 +519,8 @@ static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
     const GemmArgs& a = ra.g;
 #if RS_WPE == 2
     if (MT == 4 && !a.bsub && !a.badd && !a.content && !a.rowstat) {   // probe build: 8 waves x 32 rows instead of 4 x 64
-        hipLaunchKernelGGL((gemm_rs_kernel<2, KS, 0, 0, 2>), grid, dim3(512), 0, st, ra);
+        if (KS == 64 && a.K == 4 * KS) hipLaunchKernelGGL((gemm_rs_kernel<2, KS, 0, 0, 2, KS == 64>), grid, dim3(512), 0, st, ra);
+        else hipLaunchKernelGGL((gemm_rs_kernel<2, KS, 0, 0, 2>), grid, dim3(512), 0, st, ra);
         return check_launch("gemm_rs_kernel");
     }
 #endif
@@ -471,13 +545,13 @@ static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
         constexpr bool HOT = (MT == 4 && KS == 64) || (MT == 2 && KS == 32);
         const bool kfull = HOT && a.K == 4 * KS;
         if (a.rowstat == 1) {
-            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0, 1, HOT>), grid, dim3(256), 0, st, ra);
+            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0, 1, HOT, HOT && MT == 4 && RS_DB != 0>), grid, dim3(256), 0, st, ra);
             else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0>), grid, dim3(256), 0, st, ra);
         } else if (a.rowstat == 2) {
-            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0, 1, HOT>), grid, dim3(256), 0, st, ra);
+            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0, 1, HOT, HOT && MT == 4 && RS_DB != 0>), grid, dim3(256), 0, st, ra);
             else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0>), grid, dim3(256), 0, st, ra);
         } else {
-            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0, 1, HOT>), grid, dim3(256), 0, st, ra);
+            if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0, 1, HOT, HOT && MT == 4 && RS_DB != 0>), grid, dim3(256), 0, st, ra);
             else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0>), grid, dim3(256), 0, st, ra);
         }
     }

@@ -48,10 +48,7 @@ struct SortArgs {
 };
 
 #ifdef OPTEX_SORT_PROBE
-#ifndef SORT_PROBE_COL
-#define SORT_PROBE_COL blockIdx.x
-#endif
-#define SORT_PROBE(i) do { if (threadIdx.x == 0) a.probe[(size_t)SORT_PROBE_COL * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#define SORT_PROBE(i) do { if (threadIdx.x == 0) a.probe[(size_t)blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
 #else
 #define SORT_PROBE(i) do { } while (0)
 #endif

@@ -31,7 +31,6 @@
 //
 // Around that: histogram-equalised monotone bucket map, returning count atomics, one-barrier scan, all-equal big buckets,
 // tie list, radix fallback through the flags (sort.hip), staged sorted source column, 16-byte stores.
-#define SORT_PROBE_COL col   // (probe builds: the stamps of a column go to its own record, persistent workgroups included)
 #include "sort_common.h"
 #include <type_traits>
 
@@ -154,18 +153,8 @@ __device__ __forceinline__ void r4_count4(uint32_t& lt, uint32_t& le, const uint
 // fills all ITEMS * NT registers (no validity tests at all).
 // MODE = SORT_MATCH: out[pixel] = sorted_source[q(rank)].  MODE = SORT_EMIT (optex_sort_columns): the sorted keys and / or
 // their pixel indices, contiguous [column, n], written by rank through the (then dead) slot array.
-// PERSIST (round 5): the workgroup walks the columns blockIdx.x, blockIdx.x + gridDim.x, ... (grid = what is resident on the
-// chip) and requests the NEXT column's keys from HBM as soon as the current ones are dead — behind the rank step — so that
-// they arrive while the queue, the staging of the source column, the picks and the stores are worked off: the load phase
-// (15-24 % of a column's time in round 4's phase log, the wavefronts waiting on HBM with nothing to do) disappears from the
-// chain.  The key registers carry over the loop; the sorted source is staged without the register prefetch the one-column
-// kernel affords (those 16 registers are the next column's keys now).
-// (PERSIST runs with a 128-register budget — four waves per SIMD, ONE 1024-thread workgroup per CU: at 64 registers the carried
-// keys spilled, 154-308 VGPRs in scratch, and the kernel ran at half the speed of the one-column kernel:
-// profiles/r05_sort_persistent.md)
-// WPE: waves per SIMD the kernel is compiled for (8 = 64 registers, 4 = 128)
-template <int ITEMS, bool VEC, int NT, bool FULL, int MODE = SORT_MATCH, bool PERSIST = false, int WPE = (PERSIST ? 4 : 8)>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rank_match4_kernel(SortArgs a) {
+template <int ITEMS, bool VEC, int NT, bool FULL, int MODE = SORT_MATCH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match4_kernel(SortArgs a) {
     using K = R4<ITEMS, NT>;
     constexpr int NW = NT / 64;
     constexpr int CAP = K::CAP, NB = K::NB, NW2 = K::NW2, PER = K::PER, NWORDS = K::NWORDS, QCAP = K::QCAP,
@@ -189,10 +178,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
     constexpr uint32_t CNT_B = 0u, SLOT_B = (uint32_t)(K::CNTW + 64) * 4u, TAB_B = SLOT_B + (uint32_t)R4_TAB * 4u;
 
+    const int col = blockIdx.x, seg = col / a.C, c = col % a.C;
+    const int xseg = (a.x_n_seg == 1) ? 0 : seg;
+    const float* src = a.keys + (size_t)xseg * a.ss + (size_t)c * a.ld;
+    const int sseg = (a.src_n_seg == 1) ? 0 : seg;
+    const float* ssrt = MODE == SORT_MATCH ? a.src_sorted + ((size_t)sseg * a.C + c) * a.ns : nullptr;
+    float* o = MODE == SORT_MATCH ? a.out + (size_t)seg * a.oss + (size_t)c * a.ldo : nullptr;
     const unsigned ns = MODE == SORT_MATCH ? (unsigned)a.ns : 1u;
     const int n = FULL ? CAP : (int)a.n;
-    int tid = threadIdx.x, lane = tid & 63;   // (not const: the persistent loop makes them opaque once per column, see column())
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // VEC: the first 4 * Q registers are Q 16-byte loads (4 neighbouring pixels in one thread), the remaining T = ITEMS % 4
     // registers are scalar rows behind them (row r starts at pixel r * NT either way)
     constexpr int Q = VEC ? ITEMS / 4 : 0, T = ITEMS - 4 * Q;
@@ -205,50 +199,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     auto valid = [&](int r) { return !ragged(r) || ((VEC && T == 0) ? tid < (n >> 2) - (r >> 2) * NT : tid < n - r * NT); };
 
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) {
-        // never on this toolchain: the radix kernel would take every column
-        for (int cc = blockIdx.x; cc < a.ncols; cc += PERSIST ? gridDim.x : a.ncols)
-            if (threadIdx.x == 0) a.flags[cc] = 1;
+        if (threadIdx.x == 0) a.flags[blockIdx.x] = 1;  // never on this toolchain: the radix kernel would take every column
         return;
     }
+    SORT_PROBE(0);
     // ---- 0. the column (registers past the end hold a copy of a real key: harmless for min / max, and they stay out of
     //         every LDS update below through selects)
     float x[ITEMS];
-    auto load_keys = [&](int cc) {
-        const int sg = cc / a.C, ch = cc - sg * a.C;
-        const float* src = a.keys + (size_t)((a.x_n_seg == 1) ? 0 : sg) * a.ss + (size_t)ch * a.ld;
 #pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int e0 = (q * NT + tid) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(src + (ragged(4 * q) ? (e0 < n ? e0 : 0) : e0));
-            x[4 * q + 0] = v.x;
-            x[(4 * q + 1) % ITEMS] = v.y;
-            x[(4 * q + 2) % ITEMS] = v.z;
-            x[(4 * q + 3) % ITEMS] = v.w;
-        }
-#pragma unroll
-        for (int r = 4 * Q; r < ITEMS; r++) {
-            const int e = r * NT + tid;
-            x[r] = src[ragged(r) ? (e < n ? e : n - 1) : e];
-        }
-    };
-    // one column: `col`, with `nxt` (>= 0) the column whose keys are requested once this one's are dead
-    auto column = [&](const int col, const int nxt) {
-    const int seg = col / a.C, c = col % a.C;
-    const int sseg = (a.src_n_seg == 1) ? 0 : seg;
-    const float* ssrt = MODE == SORT_MATCH ? a.src_sorted + ((size_t)sseg * a.C + c) * a.ns : nullptr;
-    float* o = MODE == SORT_MATCH ? a.out + (size_t)seg * a.oss + (size_t)c * a.ldo : nullptr;
-    bool requested = false;
-    auto request_next = [&]() {  // (uniform) at most once per column
-        if (PERSIST && nxt >= 0 && !requested) load_keys(nxt);
-        requested = true;
-    };
-    if (PERSIST) {
-        // nothing derived from the thread index is loop-invariant for the compiler: hoisted out of the column loop, the element
-        // offsets, LDS addresses and validity masks of all phases stay live for the whole kernel — in scratch (64-VGPR budget)
-        asm volatile("" : "+v"(tid));
-        lane = tid & 63;
+    for (int q = 0; q < Q; q++) {
+        const int e0 = (q * NT + tid) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (ragged(4 * q) ? (e0 < n ? e0 : 0) : e0));
+        x[4 * q + 0] = v.x;
+        x[(4 * q + 1) % ITEMS] = v.y;
+        x[(4 * q + 2) % ITEMS] = v.z;
+        x[(4 * q + 3) % ITEMS] = v.w;
     }
-    SORT_PROBE(0);
+#pragma unroll
+    for (int r = 4 * Q; r < ITEMS; r++) {
+        const int e = r * NT + tid;
+        x[r] = src[ragged(r) ? (e < n ? e : n - 1) : e];
+    }
     for (int i = tid; i < K::CNTW; i += NT) cnt[i] = 0u;
     if (tid < RK_COARSE) c1[tid] = 0u;
     if (tid < 32) misc[tid] = 0u;
@@ -333,13 +304,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     // (red is next written by the scan of step 5, two barriers from here)
     if (!(hi < __uint_as_float(R4_INF)) || !(lo > -__uint_as_float(R4_INF))) {  // non-finite / tiny keys: radix kernel
         if (tid == 0) a.flags[col] = 1;
-        request_next();
         return;
     }
     if (lo == hi) {
         if (lo == 0.f) {  // zeros of both signs may be mixed (-0 < +0 in the specification): radix kernel
             if (tid == 0) a.flags[col] = 1;
-            request_next();
             return;
         }
         // constant column: already sorted, rank = pixel index
@@ -351,13 +320,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (a.out_idx) a.out_idx[(size_t)col * n + e] = (uint32_t)e;
             }
         }
-        request_next();
         return;
     }
     const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
     if (!(s1 > 0.f) || !(s1 < 1.0e37f)) {  // range over/underflow (8 * s1 must stay finite): radix kernel
         if (tid == 0) a.flags[col] = 1;
-        request_next();
         return;
     }
 
@@ -536,7 +503,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const unsigned nbig = misc[0];
     if (nbig > RK_MAXBIG || misc[22] != 0u) {  // (misc[22]: a non-finite or tiny key under a caller-given range, step 1)
         if (tid == 0) a.flags[col] = 1;
-        request_next();
         return;
     }
     SORT_PROBE(5);
@@ -579,7 +545,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         __syncthreads();
         if (misc[1]) {
             if (tid == 0) a.flags[col] = 1;
-            request_next();
             return;
         }
         {
@@ -691,9 +656,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
     asm volatile("" ::: "memory");
     SORT_PROBE(7);
-    // PERSIST: the keys are dead — the next column's are requested NOW and arrive while the rest of this one is worked off
-    static_assert(!PERSIST || MODE == SORT_MATCH, "SORT_EMIT writes its keys after the rank step");
-    request_next();
     // the sorted source column on its way into registers while the queue is worked off (the key registers are dead)
     const bool stage = ns <= (unsigned)CAP;
     const bool svec = VEC && (ns % 4u == 0u) && ((reinterpret_cast<uintptr_t>(ssrt) & 15u) == 0u);
@@ -704,7 +666,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     asm volatile("" : "+v"(tid9));
     r4_v4f sv[Q > 0 ? Q : 1];
     float svt[T > 0 ? T : 1];
-    if (MODE == SORT_MATCH && VEC && stage && svec && !PERSIST) {
+    if (MODE == SORT_MATCH && VEC && stage && svec) {
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const unsigned e0 = (unsigned)(q * NT + tid9) * 4u;
@@ -811,13 +773,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     //         read), each owner picks its values and leaves with 16-byte stores
     float* val = reinterpret_cast<float*>(slot);
     if (stage) {
-        if (PERSIST && svec) {
-            // (no register prefetch here: 16-byte pieces straight through, two in flight per thread; the column is shared by
-            // the batch's textures and comes from the L2 / Infinity Cache)
-#pragma unroll 2
-            for (unsigned e0 = (unsigned)tid9 * 4u; e0 < ns; e0 += (unsigned)NT * 4u)
-                R4_LDS(r4_v4f, SLOT_B + (e0 << 2)) = *reinterpret_cast<const r4_v4f*>(ssrt + e0);
-        } else if (VEC && svec) {
+        if (VEC && svec) {
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const unsigned e0 = (unsigned)(q * NT + tid9) * 4u;
@@ -857,45 +813,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if ((r & 3) == 3) asm volatile("" ::: "memory");
         }
     };
-    if (PERSIST && VEC && a.out_vec && stage) {
-        // persistent kernel: the next column's keys occupy 16 registers by now — pick and store quad by quad (four values
-        // live at a time instead of sixteen)
-        auto pick_store = [&](auto same) {
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                float v4[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int r = 4 * q + k;
-                    const unsigned rk = ragged(r) ? (valid(r) ? ba[r] : 0u) : ba[r];
-                    unsigned qi = rk;
-                    if (!decltype(same)::value) {
-                        const double aa = (double)(2u * rk + 1u) * (double)ns;
-                        qi = (unsigned)__builtin_fma(aa, a.inv_2nt, 7.450580596923828e-09);  // quantile_index (sort_common.h)
-                    }
-                    v4[k] = R4_LDS(const float, SLOT_B + (qi << 2));
-                }
-                const int e0 = (q * NT + tid9) * 4;
-                if (!ragged(4 * q) || e0 < n) *reinterpret_cast<float4*>(o + e0) = make_float4(v4[0], v4[1], v4[2], v4[3]);
-                asm volatile("" ::: "memory");
-            }
-#pragma unroll
-            for (int r = 4 * Q; r < ITEMS; r++) {
-                const unsigned rk = ragged(r) ? (valid(r) ? ba[r] : 0u) : ba[r];
-                unsigned qi = rk;
-                if (!decltype(same)::value) {
-                    const double aa = (double)(2u * rk + 1u) * (double)ns;
-                    qi = (unsigned)__builtin_fma(aa, a.inv_2nt, 7.450580596923828e-09);
-                }
-                const float vv = R4_LDS(const float, SLOT_B + (qi << 2));
-                if (valid(r)) o[r * NT + tid9] = vv;
-            }
-        };
-        if (ns == (unsigned)n) pick_store(std::true_type{});
-        else pick_store(std::false_type{});
-        SORT_PROBE(10);
-        return;
-    }
     if (stage) {
         if (ns == (unsigned)n) pick(std::true_type{}, std::true_type{});
         else pick(std::true_type{}, std::false_type{});
@@ -920,27 +837,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (valid(r)) o[r < 4 * Q ? ((r >> 2) * NT + tid9) * 4 + (r & 3) : r * NT + tid9] = v[r];
     }
     SORT_PROBE(10);
-    };  // column
-
-    if (!PERSIST) {
-        load_keys(blockIdx.x);
-        column(blockIdx.x, -1);
-        return;
-    }
-    load_keys(blockIdx.x);
-    for (int col = blockIdx.x; col < a.ncols; col += gridDim.x) {
-        const int nxt = col + (int)gridDim.x;
-        column(col, nxt < a.ncols ? nxt : -1);
-        __syncthreads();   // every LDS read of this column is done before the next one clears the counters
-    }
 }
-
-int device_cu_count();
-// (internal, not ABI: scripts/sort_time_probe.hip times the variants against each other)
-bool sort_rank4_persist = true;
-// 2: columns of more than 10240 keys on 512 threads x up to 32 keys at a 128-register budget — two workgroups (two columns) per
-// CU like the 1024-thread kernel, half the wavefronts, twice the work per wavefront
-int sort_rank4_wide = 0;
 
 template <typename KernT>
 static int launch_one4(KernT kern, DeviceOnce& once, size_t lds, const SortArgs& a, int ncols, int nt, hipStream_t st) {
@@ -971,23 +868,6 @@ static int launch_rank4_items(SortArgs a, int ncols, hipStream_t st) {
     const size_t lds = R4<ITEMS, NT>::LDS;
     const bool full = a.n == (long)ITEMS * NT;
     int rc;
-    if constexpr (MODE == SORT_MATCH && NT >= 512 && CANVEC) {
-        // the match of a batch: persistent workgroups, as many as are resident on the chip (2048 threads and 160 KiB of LDS
-        // per CU), each walking its share of the columns with the next column's keys requested behind the rank step
-        const int per_cu_t = 1024 / NT, per_cu_l = (int)(163840 / lds);   // 128 registers per thread: 1024 threads per CU
-        const long resident = (long)(per_cu_t < per_cu_l ? per_cu_t : per_cu_l) * device_cu_count();
-        if (sort_rank4_persist && in_vec && resident > 0 && ncols > resident) {
-            if (full) {
-                static DeviceOnce once;
-                rc = launch_one4(rank_match4_kernel<ITEMS, CANVEC, NT, true, MODE, true>, once, lds, a, (int)resident, NT, st);
-            } else {
-                static DeviceOnce once;
-                rc = launch_one4(rank_match4_kernel<ITEMS, CANVEC, NT, false, MODE, true>, once, lds, a, (int)resident, NT, st);
-            }
-            if (rc) return rc;
-            return check_launch("rank_match4_kernel (persistent)");
-        }
-    }
     if (in_vec && full) {
         static DeviceOnce once;
         rc = launch_one4(rank_match4_kernel<ITEMS, CANVEC, NT, true, MODE>, once, lds, a, ncols, NT, st);
@@ -1003,19 +883,6 @@ static int launch_rank4_items(SortArgs a, int ncols, hipStream_t st) {
     }
     if (rc) return rc;
     return check_launch("rank_match4_kernel");
-}
-
-// experiment: ITEMS keys per thread on 512 threads, 128 registers (full, 16-byte aligned columns only)
-template <int ITEMS, int MODE>
-static int launch_rank4_wide(SortArgs a, int ncols, hipStream_t st) {
-    constexpr int NT = 512;
-    a.out_vec = (a.ldo % 4 == 0 && a.oss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15u) == 0) ? 1 : 0;
-    const bool in_vec = a.n % 4 == 0 && a.ld % 4 == 0 && a.ss % 4 == 0 && (reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0;
-    if (!in_vec || a.n != (long)ITEMS * NT) return launch_rank4_items<16, 1024, MODE>(a, ncols, st);
-    static DeviceOnce once;
-    int rc = launch_one4(rank_match4_kernel<ITEMS, true, NT, true, MODE, false, 4>, once, R4<ITEMS, NT>::LDS, a, ncols, NT, st);
-    if (rc) return rc;
-    return check_launch("rank_match4_kernel (512 x 32)");
 }
 
 template <int MODE>
@@ -1046,9 +913,6 @@ static int launch_rank4_mode(const SortArgs& a0, int ncols, hipStream_t st) {
     // and slower: 9216 keys on 576 x 16, three workgroups of nine wavefronts to a CU, 822 us against 573 us on 1024 x 9;
     // 12544 keys on 896 x 14, 936 us against 826 us on 1024 x 13.)
     if (n == 10 * 640) return launch_rank4_items<10, 640, MODE>(a, ncols, st);
-    if constexpr (MODE == SORT_MATCH) {
-        if (sort_rank4_wide == 2 && n == 16384) return launch_rank4_wide<32, MODE>(a, ncols, st);
-    }
     switch ((int)((n + 1023) / 1024)) {
         case 6: return launch_rank4_items<6, 1024, MODE>(a, ncols, st);
         case 7: return launch_rank4_items<7, 1024, MODE>(a, ncols, st);

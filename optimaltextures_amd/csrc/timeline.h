@@ -19,22 +19,31 @@ __device__ __forceinline__ tl_ptr tl_begin(unsigned wave_slot) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
     return reinterpret_cast<tl_ptr>(((uintptr_t)hi << 32) | (uintptr_t)lo);
 }
+// (a cursor that has been through a spill comes back in vector registers: pin it to an SGPR pair again)
+__device__ __forceinline__ tl_ptr tl_uniform(tl_ptr p) {
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<tl_ptr>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+}
 // (the first wait drains the previous stamp's store — long gone — so that its data registers may be reused)
 __device__ __forceinline__ void tl_stamp(tl_ptr& p) {
     unsigned long long t;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t) : "s"(p));
+    const tl_ptr q = tl_uniform(p);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t) : "s"(q));
     p += 1;
 }
 // the constant 100 MHz clock: what a stretch of shader cycles is in time (the effective clock)
 __device__ __forceinline__ void tl_stamp_real(tl_ptr& p) {
     unsigned long long t;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t) : "s"(p));
+    const tl_ptr q = tl_uniform(p);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : "=&s"(t) : "s"(q));
     p += 1;
 }
 __device__ __forceinline__ void tl_word(tl_ptr& p, unsigned long long v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     const unsigned long long s = ((unsigned long long)hi << 32) | lo;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : : "s"(s), "s"(p));
+    const tl_ptr q = tl_uniform(p);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0" : : "s"(s), "s"(q));
     p += 1;
 }
 __device__ __forceinline__ void tl_end() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)"); }

@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
     const int C = 256, S = 64, ncols = C * S, reps = argc > 1 ? atoi(argv[1]) : 5;
     const long sizes[5][2] = {{16384, 12288}, {12544, 9408}, {9216, 6912}, {6400, 4800}, {4096, 3072}};
     const double weight[5] = {8, 9, 10, 12, 13};  // iterations per pass size (relu3_1, 512^2)
-    double tot_us[6] = {0, 0, 0, 0, 0, 0}, tot_bytes = 0;   // [persistent][range given]
+    double tot_us[2] = {0, 0}, tot_bytes = 0;
     for (int si = 0; si < 5; si++) {
         const long n = sizes[si][0], ns = sizes[si][1];
         std::vector<float> h((size_t)ncols * n), hs((size_t)C * ns), lo(ncols), hi(ncols);
@@ -42,10 +42,7 @@ int main(int argc, char** argv) {
         a.flags = flags; a.inv_2nt = 1.0 / (2.0 * n); a.ncols = ncols;
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int pg = 0; pg < (n == 16384 ? 6 : 4); pg++) {
-            const int rg = pg & 1, pe = pg >> 1;
-            optex::sort_rank4_persist = pe == 1;
-            optex::sort_rank4_wide = pe == 2 ? 2 : 0;   // 16384 keys on 512 threads x 32 keys, 128 registers   // one column per workgroup (round 4) / persistent workgroups with the next column's keys requested early (round 5)
+        for (int rg = 0; rg < 2; rg++) {
             a.rng_lo = rg ? dlo : nullptr;
             a.rng_hi = rg ? dhi : nullptr;
             float best = 1e30f, ms = 0.f;
@@ -78,16 +75,15 @@ int main(int argc, char** argv) {
                 }
             }
             const double bytes = 12.0 * n * ncols;
-            printf("n = %5ld ns = %5ld %-10s range %-6s %8.1f us  %6.2f TB/s  %.3f of 8 TB/s   flagged %d, mismatches on 6 sampled columns %d\n", n,
-                   ns, pe == 2 ? "512x32" : (pe ? "persistent" : "one-column"), rg ? "given" : "own", best * 1e3, bytes / (best * 1e9), bytes / (best * 1e9) / 8.0, nflag, bad);
-            tot_us[pg] += weight[si] * best * 1e3;
-            if (pg == 0) tot_bytes += weight[si] * bytes;
+            printf("n = %5ld ns = %5ld range %-6s %8.1f us  %6.2f TB/s  %.3f of 8 TB/s   flagged %d, mismatches on 6 sampled columns %d\n", n,
+                   ns, rg ? "given" : "own", best * 1e3, bytes / (best * 1e9), bytes / (best * 1e9) / 8.0, nflag, bad);
+            tot_us[rg] += weight[si] * best * 1e3;
+            if (rg == 0) tot_bytes += weight[si] * bytes;
         }
         hipFree(x); hipFree(out); hipFree(ss); hipFree(flags); hipFree(dlo); hipFree(dhi);
     }
-    for (int pg = 0; pg < 4; pg++)
-        printf("schedule-weighted (13/12/10/9/8 iterations), %-10s range %-6s: %.2f ms per step, %.2f TB/s = %.3f of HBM peak\n",
-               (pg >> 1) ? "persistent" : "one-column", (pg & 1) ? "given" : "own", tot_us[pg] * 1e-3, tot_bytes / (tot_us[pg] * 1e6),
-               tot_bytes / (tot_us[pg] * 1e6) / 8.0);
+    for (int rg = 0; rg < 2; rg++)
+        printf("schedule-weighted (13/12/10/9/8 iterations), range %-6s: %.2f ms per step, %.2f TB/s = %.3f of HBM peak\n",
+               rg ? "given" : "own", tot_us[rg] * 1e-3, tot_bytes / (tot_us[rg] * 1e6), tot_bytes / (tot_us[rg] * 1e6) / 8.0);
     return 0;
 }
