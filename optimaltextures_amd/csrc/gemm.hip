@@ -552,24 +552,13 @@ template <bool BPM, bool OPM>
 static int launch_layout(GemmArgs& a, bool vec, int n_cu, hipStream_t st) {
     const long long big = (long long)((a.M + 127) / 128) * ((a.n + 127) / 128) * a.n_seg;
     if (a.sym) return launch_cfg<64, 64, 16, 2, 2, BPM, OPM>(a, vec, st);  // square tiles: the mirrored store needs BM == BN
-    // Channel-major rotations of the hot loop.  Both hot kernels run at the chip's power-managed clock on dense data
-    // (profiles/r03_gemm_power_dvfs.md: 2.11-2.13 GHz, MFMA duty 0.74-0.76 either way); the 256 x 128 LDS-tiled kernel is
-    // 2-5 % ahead where it fits exactly (192 < M, K <= 256, multiples of 4), the R-stationary one everywhere else in
-    // 64 < M <= 256, 64 <= K <= 256: PCA ranks (M = K = 181: 86 vs 60 TFLOP/s of useful flops), project / unproject
-    // (181 x 256: 93 vs 67), 192 x 192 (89 vs 78), relu2_1's ranks (k ~ 84 of C = 128).
-    if (!BPM && !OPM && gemm_rs_enabled && gemm_rs_supported(a, n_cu)) {
-        bool lds_fits = a.M > 192 && a.K > 192 && a.M % 4 == 0 && vec && a.a_vec && hot_shape(a, n_cu) && output_vec(a);
-        if (lds_fits) {
-            // Small batches (BASELINE config 4 shards 8 textures per GPU): a launch is a handful of 128-pixel tiles per CU
-            // and its time is the LARGEST number of tiles a CU gets — 576 tiles on 256 CUs take as long as 768.  The
-            // R-stationary kernel cuts the map into 64-pixel tiles: where that rounds markedly better (it is ~4 % behind at
-            // steady state) it takes the launch.  Both kernels give the same bits.
-            auto filled = [n_cu](long long tiles) { return (double)tiles / (double)(((tiles + n_cu - 1) / n_cu) * n_cu); };
-            const long long t128 = (long long)(a.n / 128) * a.n_seg, t64 = (long long)(a.n / 64) * a.n_seg;
-            if (filled(t64) >= filled(t128) + 0.06) lds_fits = false;
-        }
-        if (!lds_fits || gemm_rs_force) return gemm_rs_launch(a, n_cu, st);
-    }
+    // Channel-major rotations of the hot loop: the R-stationary kernel (gemm_rs.hip) takes every launch it supports — since round 5
+    // (matrix in AGPRs, LDS-staged prologue, double-buffered accumulators) it is ahead of the 256 x 128 LDS-tiled kernel at every
+    // shape of the schedule: [64, 256, 16384] gaussian 122.0 against 112.1 TFLOP/s, [64, 256, 4096] 101.3 against 98.0, and at 8
+    // textures per step 49 / 103 / 161 us against 57 / 122 / 170 us at 4096 / 9216 / 16384 pixels (profiles/r05_gemm_probes.md);
+    // it has no tile quantisation in M or K beyond 16 rows and 4 k either (PCA ranks: M = K = 181: 86 against 60 TFLOP/s).
+    // gemm16_cm_kernel keeps what the R-stationary kernel does not take (bias / blend / centring with M > 192, n % 64 != 0, ...).
+    if (!BPM && !OPM && gemm_rs_enabled && gemm_rs_supported(a, n_cu)) return gemm_rs_launch(a, n_cu, st);
     if (big >= 2LL * n_cu && a.M > 64) {
         const long long huge = (long long)((a.M + 255) / 256) * ((a.n + 127) / 128) * a.n_seg;
         if (!BPM && !OPM && vec && a.a_vec && hot_shape(a, n_cu) && output_vec(a)) {

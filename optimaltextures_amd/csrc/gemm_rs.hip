@@ -59,6 +59,23 @@ __device__ __forceinline__ rs_gptr rs_uniform(const void* p) {
     return reinterpret_cast<rs_gptr>(((uintptr_t)hi << 32) | (uintptr_t)lo);
 }
 
+// the value of lane (l ^ 16) / (l ^ 32), on the VALU: v_permlane16_swap / v_permlane32_swap of a register with itself (odd rows of
+// the first operand <-> even rows of the second; upper half of the first <-> lower half of the second) leave the partner's value in
+// one of the two results on every lane.  __shfl_xor is a ds_bpermute: an LDS round trip behind s_waitcnt lgkmcnt(0) — inside the
+// k-loop of the double-buffered kernels each of them stalled the matrix pipe (round 5: the row-statistics variant ran 39.1
+// thousand cycles per tile against 36.4 without statistics)
+// (both results are combined, so the code does not depend on which of the two is the lane's own value: min, max and + commute)
+__device__ __forceinline__ void rs_pair16(float v, float& p, float& q) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    p = __uint_as_float(r[0]);   // (row0, row0, row2, row2)
+    q = __uint_as_float(r[1]);   // (row1, row1, row3, row3)
+}
+__device__ __forceinline__ void rs_pair32(float v, float& p, float& q) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    p = __uint_as_float(r[0]);   // (lower half, lower half)
+    q = __uint_as_float(r[1]);   // (upper half, upper half)
+}
+
 constexpr int RS_BN = 64;     // pixels per tile (4 sub-tiles of 16)
 #ifndef RS_DEPTH_VALUE
 #define RS_DEPTH_VALUE 16
@@ -343,10 +360,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
                             mn = fminf(mn, v[r][j]);
                             mx = fmaxf(mx, v[r][j]);
                         }
-                    mn = fminf(mn, __shfl_xor(mn, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mn = fminf(mn, __shfl_xor(mn, 32));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float p, q;
+                    rs_pair16(mn, p, q); mn = fminf(p, q);
+                    rs_pair16(mx, p, q); mx = fmaxf(p, q);
+                    rs_pair32(mn, p, q); mn = fminf(p, q);
+                    rs_pair32(mx, p, q); mx = fmaxf(p, q);
                     if (kq == 0 && ok) {
                         a.rs_a[pidx] = mn;
                         a.rs_b[pidx] = mx;
@@ -357,8 +375,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
                     for (int r = 0; r < 4; r++)
 #pragma unroll
                         for (int j = 0; j < 4; j++) sm = sm + v[r][j];
-                    sm = sm + __shfl_xor(sm, 16);
-                    sm = sm + __shfl_xor(sm, 32);
+                    float p, q;
+                    rs_pair16(sm, p, q); sm = p + q;
+                    rs_pair32(sm, p, q); sm = p + q;
                     if (kq == 0 && ok) a.rs_a[pidx] = sm;
                 }
             }
