@@ -450,6 +450,20 @@ class OptimalTexture(torch.nn.Module):
             out.append((resized, feats, [torch.empty((0, 0), device=f.device) for f in feats], hws))
         return out
 
+    def rotation_schedule(self, sides=None):
+        """[(C, iterations), ...] of a forward() call in the order the loops ask for their rotations (pass-major, encoder-
+        minor, the colour-transfer draw last).  Without PCA it follows from the layer lists alone; with PCA the kept ranks
+        are those of `sides` (prefetch_style_sides), which must then be given."""
+        schedule = []
+        for p in range(self.passes):
+            for li, encoder in enumerate(self.encoders):
+                enc_index = li if self.index_by_position else 5 - encoder.depth
+                c = int(sides[p][2][li].shape[1]) if self.use_pca else encoder.out_shape(16, 16)[0]
+                schedule.append((c, layer_iters(self.iters_per_pass_and_layer, p, enc_index)))
+        if self.color_transfer == "opt":
+            schedule.append((3, 3))
+        return schedule
+
     def encode_inputs(self, pastiche: Tensor, styles: List[Tensor], content: Optional[Tensor], size: int,
                       style_side=None):
         resized = self._needs_resize(pastiche.shape[-2:], size)

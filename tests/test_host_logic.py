@@ -280,3 +280,16 @@ def test_polar_method_is_parallel_over_four_word_attempts():
         probe = np.random.RandomState(seed)
         probe.randint(0, 2 ** 32, size=consumed, dtype=np.uint32)
         assert np.array_equal(probe.get_state()[1], ref.get_state()[1]) and probe.get_state()[2] == ref.get_state()[2]
+
+
+def test_rotation_schedule_of_a_forward_call():
+    """OptimalTexture.rotation_schedule: (C, iterations) per (pass, layer) in the order the loops ask for their rotations — what
+    bench.py prefetches a step ahead (rotation.DeviceNormals.prefetch) and forward() checks with DeviceNormals.covers().  The
+    headline configuration: relu3_1 only, no_pca, 13 / 12 / 10 / 9 / 8 iterations at C = 256 (util.py:68-86 read through
+    optex.py:112)."""
+    from optimaltextures_amd.driver import OptimalTexture
+    tex = OptimalTexture(size=512, iters=500, passes=5, hist_mode="cdf", no_pca=True, layers=(3,), independent=True)
+    assert tex.rotation_schedule() == [(256, 13), (256, 12), (256, 10), (256, 9), (256, 8)]
+    tex = OptimalTexture(size=256, iters=500, passes=2, hist_mode="cdf", no_pca=True, layers=(3, 1), color_transfer="opt")
+    sched = tex.rotation_schedule()
+    assert [c for c, _ in sched] == [256, 64, 256, 64, 3] and sched[-1] == (3, 3) and all(k > 0 for _, k in sched)
