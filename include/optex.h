@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 7
+#define OPTEX_ABI_VERSION 8
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -45,6 +45,13 @@ int optex_abi_version(void);
 const char* optex_last_error(void);
 /* multiProcessorCount / LDS bytes per block of the current device (diagnostics for bench.py) */
 int optex_device_info(int* n_cu, int* lds_bytes, int* wavefront);
+/* ABI 8.  The R-stationary rotation GEMM is a persistent kernel: one workgroup per compute unit, each needing a WHOLE CU (all of
+ * its registers).  A small kernel of another stream that sits on one CU — the rotation generator's sequential MT19937 walk, an
+ * RCCL broadcast — then leaves one workgroup of every GEMM launch waiting for a CU: its tiles start when another workgroup has
+ * finished, and the launch takes twice as long (measured at 8 textures per step: 46.3 ms per step against 43.8 without the
+ * generator).  `spare` CUs are left out of the GEMM's grid (default 1: 0.4 % more work per workgroup, nothing to wait for);
+ * 0 restores one workgroup on every CU.  Returns the previous value; process-wide, takes effect with the next launch. */
+int optex_gemm_spare_cus(int spare);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1  rotation / apply GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).

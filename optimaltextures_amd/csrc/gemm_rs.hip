@@ -97,6 +97,8 @@ constexpr int RS_DEPTH_DB = RS_DEPTH_DB_VALUE;
 #endif
 constexpr int RS_RAG = 16;    // the last RS_RAG k-steps of an instantiation may lie (partly) beyond K
 
+extern int gemm_rs_spare_cus;   // CUs left out of the persistent grid (optex_gemm_spare_cus)
+
 struct RsArgs {
     GemmArgs g;
     int tiles_n;          // pixel tiles per segment (n / 64)
@@ -584,7 +586,12 @@ int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
     ra.segs_per_group = a.at_ss == 0 ? a.n_seg : 1;
     const int groups = a.n_seg / ra.segs_per_group;
     const long per_group = (long)ra.tiles_n * ra.segs_per_group;
-    long gx = (n_cu + groups - 1) / groups;  // one workgroup per CU over all groups
+    // one workgroup per CU over all groups, minus the spare CUs (include/optex.h, optex_gemm_spare_cus: a workgroup needs a whole
+    // CU, and a CU held by a small kernel of another stream would make it the launch's straggler)
+    int cus = n_cu - gemm_rs_spare_cus;
+    if (cus < n_cu / 2) cus = n_cu / 2;
+    if (cus < 1) cus = 1;
+    long gx = (cus + groups - 1) / groups;
     if (gx > per_group) gx = per_group;
     ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                    4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));
@@ -605,5 +612,13 @@ int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
 }
 
 }  // namespace optex
+
+namespace optex { int gemm_rs_spare_cus = 1; }
+
+extern "C" int optex_gemm_spare_cus(int spare) {
+    const int old = optex::gemm_rs_spare_cus;
+    optex::gemm_rs_spare_cus = spare < 0 ? 0 : spare;
+    return old;
+}
 
 TL_DEFINE_SETTER(tl_set_rs)

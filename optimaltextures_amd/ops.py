@@ -313,3 +313,10 @@ def profile_collect():
     check(lib.optex_prof_collect(k, ms, ln, fl, by))
     return {lib.optex_prof_class_name(i).decode(): dict(ms=ms[i], launches=int(ln[i]), flops=fl[i], bytes=by[i])
             for i in range(k) if ln[i]}
+
+
+def gemm_spare_cus(spare: int) -> int:
+    """CUs the persistent rotation GEMM leaves out of its grid (include/optex.h, optex_gemm_spare_cus; default 1: a small kernel
+    of another stream — the rotation generator, an RCCL broadcast — then never makes one of its workgroups wait for a CU).
+    Returns the previous value."""
+    return int(_lib.load().optex_gemm_spare_cus(int(spare)))

@@ -71,6 +71,16 @@ def main():
             host_a = time.perf_counter() - t0
             torch.cuda.synchronize()
             aht = time.perf_counter() - t0
+            # device stream with one workgroup of the persistent GEMM on EVERY CU (spare = 0: what rounds 3-4 did)
+            from optimaltextures_amd import ops as _ops
+            prev = _ops.gemm_spare_cus(0)
+            run_dev(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_dev(steps)
+            torch.cuda.synchronize()
+            dev0 = time.perf_counter() - t0
+            _ops.gemm_spare_cus(prev)
             # the same steps with every rotation batch of the call served from a device-side cache
             cache, own = {}, rotation.rotations
 
@@ -99,6 +109,7 @@ def main():
         draw = time.perf_counter() - t0
         print(f"B = {B:3d}: host stream {B * steps / live:7.1f} textures/s ({1e3 * live / steps:6.1f} ms/step, host enqueue {1e3 * host / steps:6.1f} ms) | "
               f"device stream {B * steps / devt:7.1f} textures/s ({1e3 * devt / steps:6.1f} ms/step, host enqueue {1e3 * host_d / steps:6.1f} ms) | "
+              f"device stream, no spare CU in the GEMM grid {B * steps / dev0:7.1f} textures/s ({1e3 * dev0 / steps:6.1f} ms/step) | "
               f"device stream a step ahead {B * steps / aht:7.1f} textures/s ({1e3 * aht / steps:6.1f} ms/step, host enqueue {1e3 * host_a / steps:6.1f} ms) | "
               f"cached rotations {B * steps / gpu:7.1f} textures/s ({1e3 * gpu / steps:6.1f} ms/step, host enqueue {1e3 * host_c / steps:6.1f} ms) | "
               f"drawing one step's 1.71 M normals on the host: {1e3 * draw:.1f} ms")
