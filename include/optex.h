@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 8
+#define OPTEX_ABI_VERSION 9
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
@@ -52,6 +52,12 @@ int optex_device_info(int* n_cu, int* lds_bytes, int* wavefront);
  * generator).  `spare` CUs are left out of the GEMM's grid (default 1: 0.4 % more work per workgroup, nothing to wait for);
  * 0 restores one workgroup on every CU.  Returns the previous value; process-wide, takes effect with the next launch. */
 int optex_gemm_spare_cus(int spare);
+/* ABI 9.  optex_cdf_match / the cdf iteration of optex_ot_loop run range + histograms + LUT + interpolation of a column as ONE
+ * kernel that keeps the column in registers (columns of at most 16384 values, 16-byte aligned rows, one workgroup per column:
+ * every batched call of the hot loop) — the target is read from HBM once instead of twice.  `on` = 0 forces the two-kernel
+ * pipeline (cdf_hist_lut_kernel + cdf_apply_kernel: what longer or chunked columns take anyway), the same bits either way
+ * (tests/test_gpu_parity.py compares them).  Returns the previous value; process-wide, default 1. */
+int optex_cdf_fused(int on);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1  rotation / apply GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).

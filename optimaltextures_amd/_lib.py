@@ -7,7 +7,7 @@ import torch  # imported BEFORE the CDLL so the library binds to the HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liboptex_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 CHANNEL_MAJOR, PIXEL_MAJOR = 0, 1
 
 _c = ctypes
@@ -19,6 +19,7 @@ SIGNATURES = {
     "optex_last_error": (_c.c_char_p, []),
     "optex_device_info": (_I, [_P, _P, _P]),
     "optex_gemm_spare_cus": (_I, [_I]),
+    "optex_cdf_fused": (_I, [_I]),
     "optex_gemm_tn": (_I, [_P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _I, _I, _I, _L, _I, _P, _L, _P, _L, _P, _F, _P]),
     "optex_col_minmax": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
     "optex_col_histc": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _P]),

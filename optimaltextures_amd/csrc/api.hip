@@ -124,7 +124,7 @@ ProfScope::~ProfScope() {
 static const char* kClassNames[KC_COUNT] = {"gemm_tn", "col_minmax", "col_hist", "cdf_lut", "cdf_apply", "sort_columns",
                                             "sort_match", "col_mean", "gram", "cov_finalize", "householder", "interp",
                                             "sort_radix_sweep", "vgg_glue", "linalg_gemm", "chol_inv", "ns_init",
-                                            "legacy_normals"};
+                                            "legacy_normals", "cdf_match"};
 
 }  // namespace optex
 

@@ -189,20 +189,32 @@ __device__ __forceinline__ void hist_add(unsigned* h, float v, float lo, float h
 }
 
 template <bool FAST>
+__device__ __forceinline__ void hist_add4(unsigned* h, const float4 v, float hl, float hu, float range, float inv) {
+    hist_add<FAST>(h, v.x, hl, hu, range, inv);
+    hist_add<FAST>(h, v.y, hl, hu, range, inv);
+    hist_add<FAST>(h, v.z, hl, hu, range, inv);
+    hist_add<FAST>(h, v.w, hl, hu, range, inv);
+}
+
+// Four 16-byte loads in flight per thread (round 5: the plain loop compiled to load -> s_waitcnt vmcnt(0) -> 4 atomics, ONE
+// kilobyte in flight per wavefront — 32 KB per CU where ~60 KB cover the HBM round trip at full rate)
+template <bool FAST>
 __device__ __forceinline__ void hist_chunk_t(unsigned* h, const float* __restrict__ p, long beg, long end, int vec, float hl, float hu,
                                              float range, float inv) {
     const int tid = threadIdx.x;
     if (vec) {  // beg is a multiple of 4 and rows are 16-byte aligned
         const long nv = (end - beg) / 4;
         const float4* p4 = reinterpret_cast<const float4*>(p + beg);
-        for (long i = tid; i < nv; i += 256) {
-            const float4 v = p4[i];
-            hist_add<FAST>(h, v.x, hl, hu, range, inv);
-            hist_add<FAST>(h, v.y, hl, hu, range, inv);
-            hist_add<FAST>(h, v.z, hl, hu, range, inv);
-            hist_add<FAST>(h, v.w, hl, hu, range, inv);
+        long i = tid;
+        for (; i + 768 < nv; i += 1024) {
+            const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+            hist_add4<FAST>(h, v0, hl, hu, range, inv);
+            hist_add4<FAST>(h, v1, hl, hu, range, inv);
+            hist_add4<FAST>(h, v2, hl, hu, range, inv);
+            hist_add4<FAST>(h, v3, hl, hu, range, inv);
         }
-        for (long i = beg + nv * 4 + tid; i < end; i += 256) hist_add<FAST>(h, p[i], hl, hu, range, inv);
+        for (; i < nv; i += 256) hist_add4<FAST>(h, p4[i], hl, hu, range, inv);
+        for (long j = beg + nv * 4 + tid; j < end; j += 256) hist_add<FAST>(h, p[j], hl, hu, range, inv);
     } else {
         for (long i = beg + tid; i < end; i += 256) hist_add<FAST>(h, p[i], hl, hu, range, inv);
     }
@@ -251,27 +263,44 @@ struct LutShared {
     float tcdf[kBins], scdf[kBins], edges[kBins], rm[kBins];
 };
 
-// histmatch.py:59-67 for one column: ht / hs = the two counts of bin i = threadIdx.x; l = the column's LUT; d = NULL or the
-// column's debug record.  All 256 threads of the block call it.
+// histmatch.py:59-67 for one column: ht / hs = the two counts of bin i = threadIdx.x; l = the column's LUT in global memory
+// (or NULL: the caller keeps it on the CU); d = NULL or the column's debug record.  All 256 threads of the block call it;
+// thread i returns with remapped_cdf[i] in `r_out` and the slope of bin i in `slope_out`, S.edges / S.rm hold the tables.
 __device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned hs, float lo, float hi, float* __restrict__ l,
-                                           float* __restrict__ d) {
-    const int i = threadIdx.x;
-    S.ct[i] = ht;
-    S.cs[i] = hs;
+                                           float* __restrict__ d, float& r_out, float& slope_out) {
+    const int i = threadIdx.x, lane = i & 63, w = i >> 6;
     S.rt[i] = ht;
     S.rs[i] = hs;
-    __syncthreads();
-    // inclusive scan (Hillis-Steele); integer, hence exact and equal to torch's fp32 cumsum while totals < 2^24
-    for (int off = 1; off < kBins; off <<= 1) {
-        const unsigned a = (i >= off) ? S.ct[i - off] : 0u, b = (i >= off) ? S.cs[i - off] : 0u;
-        __syncthreads();
-        S.ct[i] += a;
-        S.cs[i] += b;
-        __syncthreads();
+    // inclusive scan: inside the wavefront by lane shifts, the three wave totals through LDS (one barrier; the Hillis-Steele
+    // scan over LDS this replaces had sixteen); integer, hence exact and equal to torch's fp32 cumsum while totals < 2^24
+    unsigned ct = ht, cs = hs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned a = __shfl_up(ct, o), b = __shfl_up(cs, o);
+        if (lane >= o) {
+            ct += a;
+            cs += b;
+        }
     }
-    float ft = (float)S.ct[i], fs = (float)S.cs[i];
-    float tl = (float)S.ct[kBins - 1], sl = (float)S.cs[kBins - 1];
-    if (S.ct[kBins - 1] >= (1u << 24) || S.cs[kBins - 1] >= (1u << 24)) {
+    if (lane == 63) {
+        S.ct[w] = ct;
+        S.cs[w] = cs;
+    }
+    __syncthreads();
+    unsigned tot_t = 0, tot_s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned a = S.ct[k], b = S.cs[k];
+        if (k < w) {
+            ct += a;
+            cs += b;
+        }
+        tot_t += a;
+        tot_s += b;
+    }
+    float ft = (float)ct, fs = (float)cs;
+    float tl = (float)tot_t, sl = (float)tot_s;
+    if (tot_t >= (1u << 24) || tot_s >= (1u << 24)) {
         // beyond 2^24 the reference's sequential fp32 cumsum rounds: replay it literally
         __syncthreads();
         if (i == 0) {
@@ -304,9 +333,13 @@ __device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned h
     __syncthreads();
     const int nxt = (i + 1 > kBins - 1) ? kBins - 1 : i + 1;
     const float slope = __fdiv_rn(S.rm[nxt] - S.rm[i], S.edges[nxt] - S.edges[i]);
-    l[i] = S.edges[i];
-    l[kBins + i] = r;
-    l[2 * kBins + i] = slope;
+    r_out = r;
+    slope_out = slope;
+    if (l) {
+        l[i] = S.edges[i];
+        l[kBins + i] = r;
+        l[2 * kBins + i] = slope;
+    }
     if (d) {
         if (i == 0) {
             d[0] = lo;
@@ -349,7 +382,7 @@ struct HistLutArgs {
     int vec_t, vec_s;
 };
 
-__global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void cdf_hist_lut_kernel(HistLutArgs a) {
     const int col = blockIdx.x, seg = col / a.C, c = col % a.C, tid = threadIdx.x;
     __shared__ unsigned sh[4][kBins];
     __shared__ float slo[4], shi[4];
@@ -415,7 +448,8 @@ __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
             a.lo[col] = lo;
             a.hi[col] = hi;
         }
-        lut_column(S, ht, hs, lo, hi, l, d);
+        float r_, sl_;
+        lut_column(S, ht, hs, lo, hi, l, d, r_, sl_);
         return;
     }
     const int nblk = a.chunks_t + a.chunks_s, y = (int)blockIdx.y;
@@ -444,29 +478,44 @@ __global__ __launch_bounds__(256) void cdf_hist_lut_kernel(HistLutArgs a) {
         a.lo[col] = lo;
         a.hi[col] = hi;
     }
-    lut_column(S, ht, hs, lo, hi, l, d);
+    float r_, sl_;
+    lut_column(S, ht, hs, lo, hi, l, d, r_, sl_);
 }
 
 // ------------------------------------------------------------------------------------------------ K3 apply
 // out = interp(target_channel, bin_edges, remapped_cdf)   histmatch.py:68
-__device__ __forceinline__ float lut_apply(float x, float lo, float range256, const float* e, const float* rm,
-                                           const float* sl) {
+// The LUT sits in LDS as one 16-byte entry per bin: T[idx] = (edges[idx - 1] (NaN for idx = 0), edges[idx], remapped[idx],
+// slope[idx]) — the candidate bin's entry answers "is this searchsorted_left(edges, x)?" AND carries everything the
+// interpolation needs, ONE ds_read_b128 per element where three separate tables took five to six ds_read_b32 (round 5: the
+// kernel was bound by those reads, 0.65 LDS cycles per element against 0.61 for the HBM stream at peak).
+__device__ __forceinline__ float lut_apply(float x, float lo, float range256, const float4* T) {
     // candidate bin from the histogram formula, then an exact fix-up to idx = searchsorted_left(edges, x)
     int idx = 0;
     if (range256 > 0.f) {
         const float t = (x - lo) * range256;
         idx = (t >= 0.f) ? ((t < 255.f) ? (int)t : 255) : 0;
     }
-    while (idx > 0 && e[idx - 1] >= x) idx--;
-    while (idx < kBins - 1 && !(e[idx] >= x)) idx++;
-    const int nxt = (idx + 1 > kBins - 1) ? kBins - 1 : idx + 1;
-    const float slope = sl[idx];
-    float f = __fadd_rn(__fmul_rn(slope, x - e[idx]), rm[idx]);
+    float4 q = T[idx];
+    if (q.x >= x || (idx < kBins - 1 && !(q.y >= x))) {   // rare: the candidate is a neighbour of the bin (or x is NaN)
+        while (idx > 0 && T[idx].x >= x) idx--;
+        while (idx < kBins - 1 && !(T[idx].y >= x)) idx++;
+        q = T[idx];
+    }
+    float f = __fadd_rn(__fmul_rn(q.w, x - q.y), q.z);
     if (!finite_f(f)) {
-        const float f2 = __fadd_rn(__fmul_rn(slope, x - e[nxt]), rm[nxt]);
-        f = finite_f(f2) ? f2 : rm[idx];
+        const float4 q2 = T[(idx + 1 > kBins - 1) ? kBins - 1 : idx + 1];
+        const float f2 = __fadd_rn(__fmul_rn(q.w, x - q2.y), q2.z);
+        f = finite_f(f2) ? f2 : q.z;
     }
     return f;
+}
+__device__ __forceinline__ float4 lut_apply4(const float4 v, float lo, float range256, const float4* T) {
+    float4 r;
+    r.x = lut_apply(v.x, lo, range256, T);
+    r.y = lut_apply(v.y, lo, range256, T);
+    r.z = lut_apply(v.z, lo, range256, T);
+    r.w = lut_apply(v.w, lo, range256, T);
+    return r;
 }
 
 __global__ __launch_bounds__(256) void cdf_apply_kernel(const float* __restrict__ x, long ld, long seg_stride, long n,
@@ -474,13 +523,10 @@ __global__ __launch_bounds__(256) void cdf_apply_kernel(const float* __restrict_
                                                         const float* __restrict__ hi_, const float* __restrict__ lut,
                                                         float* __restrict__ out, long ldo, long o_seg_stride, int vec) {
     const int col = blockIdx.x, seg = col / C, c = col % C;
-    __shared__ float e[kBins], rm[kBins], sl[kBins];
+    __shared__ float4 T[kBins];
     const float* l = lut + (size_t)col * 3 * kBins;
-    for (int i = threadIdx.x; i < kBins; i += blockDim.x) {
-        e[i] = l[i];
-        rm[i] = l[kBins + i];
-        sl[i] = l[2 * kBins + i];
-    }
+    for (int i = threadIdx.x; i < kBins; i += blockDim.x)
+        T[i] = make_float4(i > 0 ? l[i - 1] : __uint_as_float(0x7fc00000u), l[i], l[kBins + i], l[2 * kBins + i]);
     __syncthreads();
     const float lo = lo_[col], hi = hi_[col];
     const float range = hi - lo;
@@ -492,20 +538,119 @@ __global__ __launch_bounds__(256) void cdf_apply_kernel(const float* __restrict_
         const long nv = (end - beg) / 4;
         const float4* p4 = reinterpret_cast<const float4*>(p + beg);
         float4* o4 = reinterpret_cast<float4*>(o + beg);
-        for (long i = threadIdx.x; i < nv; i += blockDim.x) {
-            const float4 v = p4[i];
-            float4 r;
-            r.x = lut_apply(v.x, lo, range256, e, rm, sl);
-            r.y = lut_apply(v.y, lo, range256, e, rm, sl);
-            r.z = lut_apply(v.z, lo, range256, e, rm, sl);
-            r.w = lut_apply(v.w, lo, range256, e, rm, sl);
-            o4[i] = r;
+        long i = threadIdx.x;
+        for (; i + 768 < nv; i += 1024) {   // four 16-byte loads in flight per thread (all read before the first store: in place is safe)
+            const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+            o4[i] = lut_apply4(v0, lo, range256, T);
+            o4[i + 256] = lut_apply4(v1, lo, range256, T);
+            o4[i + 512] = lut_apply4(v2, lo, range256, T);
+            o4[i + 768] = lut_apply4(v3, lo, range256, T);
         }
-        for (long i = beg + nv * 4 + threadIdx.x; i < end; i += blockDim.x)
-            o[i] = lut_apply(p[i], lo, range256, e, rm, sl);
+        for (; i < nv; i += 256) o4[i] = lut_apply4(p4[i], lo, range256, T);
+        for (long j = beg + nv * 4 + threadIdx.x; j < end; j += 256) o[j] = lut_apply(p[j], lo, range256, T);
     } else {
-        for (long i = beg + threadIdx.x; i < end; i += blockDim.x) o[i] = lut_apply(p[i], lo, range256, e, rm, sl);
+        for (long i = beg + threadIdx.x; i < end; i += 256) o[i] = lut_apply(p[i], lo, range256, T);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ K2 + K3 in one launch
+// Range, both histograms, the LUT AND the interpolation of a column in one workgroup that keeps the column in REGISTERS
+// (round 5): a column of the hot loop is at most 16384 values = 16 float4 per thread, so the target is read from HBM once —
+// binned from the registers, matched from the registers, stored — instead of once by the histogram kernel and once more by the
+// apply kernel: 8 bytes per element instead of 12 (24 instead of 28 per element and iteration of the whole cdf step), three
+// launches per iteration instead of four, and all NV loads of a thread are in flight together.  The LUT never leaves the CU.
+// Same arithmetic as cdf_hist_lut_kernel + cdf_apply_kernel, statement for statement (they stay: columns longer than 16384
+// values or cut into chunks, unaligned rows).  grid = (columns); nt % 4 == 0, nt <= 1024 NV, rows 16-byte aligned.
+// (registers: NV float4 of column + ~40; columns up to 10240 values run five workgroups per CU, the longest four)
+template <int NV>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NV <= 2 ? 8 : (NV <= 10 ? 5 : 4)))) void cdf_fused_kernel(HistLutArgs a, float* __restrict__ out, long ldo, long oss) {
+    const int col = blockIdx.x, seg = col / a.C, c = col % a.C, tid = threadIdx.x;
+    __shared__ unsigned sh[4][kBins];
+    __shared__ float slo[4], shi[4];
+    __shared__ LutShared S;
+    __shared__ float4 T[kBins];
+    const float* pt = a.t + (size_t)seg * a.tss + (size_t)c * a.ldt;
+    const float4* p4 = reinterpret_cast<const float4*>(pt);
+    const int nv = (int)(a.nt / 4);
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (tid + 256 * k < nv) v[k] = p4[tid + 256 * k];
+    for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
+    float lo, hi;
+    bool src_range = false;
+    if (a.pmn) {
+        lo = INFINITY;
+        hi = -INFINITY;
+        const float* pa = a.pmn + (size_t)seg * a.parts * a.C + c;
+        const float* pb = a.pmx + (size_t)seg * a.parts * a.C + c;
+        for (int p = tid; p < a.parts; p += 256) {
+            lo = fminf(lo, pa[(size_t)p * a.C]);
+            hi = fmaxf(hi, pb[(size_t)p * a.C]);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if ((tid & 63) == 0) {
+            slo[tid >> 6] = lo;
+            shi[tid >> 6] = hi;
+        }
+        __syncthreads();
+        const int oc = ((a.src_n_seg == 1) ? 0 : seg) * a.C + c;
+        const float smn = a.smn[oc], smx = a.smx[oc];
+        lo = fminf(fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), smn);   // histmatch.py:52-53
+        hi = fmaxf(fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3])), smx);
+        src_range = a.shist != nullptr && lo == smn && hi == smx;   // uniform over the block
+    } else {
+        lo = a.lo[col];
+        hi = a.hi[col];
+        __syncthreads();
+    }
+    float hl = lo, hu = hi;
+    if (hl == hu) {  // torch.histc widens an empty range
+        hl -= 1.0f;
+        hu += 1.0f;
+    }
+    const float range = hu - hl;
+    unsigned* h = sh[tid >> 6];
+    if (div_by_ok(range)) {
+        const float inv = __fdiv_rn(1.0f, range);
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            if (tid + 256 * k < nv) hist_add4<true>(h, v[k], hl, hu, range, inv);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            if (tid + 256 * k < nv) hist_add4<false>(h, v[k], hl, hu, range, 0.f);
+    }
+    __syncthreads();
+    const unsigned ht = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    unsigned hs;
+    if (src_range) {
+        hs = a.shist[((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * kBins + tid];
+    } else {
+        const float* ps = a.s + (size_t)((a.src_n_seg == 1) ? 0 : seg) * a.sss + (size_t)c * a.lds;
+        __syncthreads();
+        for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
+        __syncthreads();
+        hist_chunk(h, ps, 0, a.ns, a.vec_s, hl, hu, range);
+        __syncthreads();
+        hs = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    }
+    if (tid == 0) {
+        a.lo[col] = lo;
+        a.hi[col] = hi;
+    }
+    float* d = a.dbg ? a.dbg + (size_t)col * (2 + 4 * kBins) : nullptr;
+    float r, slope;
+    lut_column(S, ht, hs, lo, hi, nullptr, d, r, slope);
+    T[tid] = make_float4(tid > 0 ? S.edges[tid - 1] : __uint_as_float(0x7fc00000u), S.edges[tid], r, slope);
+    __syncthreads();
+    const float arange = hi - lo;
+    const float range256 = (arange > 0.f) ? 256.f / arange : 0.f;
+    float4* o4 = reinterpret_cast<float4*>(out + (size_t)seg * oss + (size_t)c * ldo);
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (tid + 256 * k < nv) o4[tid + 256 * k] = lut_apply4(v[k], lo, range256, T);
 }
 
 // ------------------------------------------------------------------------------------------------ any bin count
@@ -656,6 +801,8 @@ __global__ void interp_kernel(const float* __restrict__ x, long nx, const float*
 // ------------------------------------------------------------------------------------------------ host side
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static int cdf_fused_enabled = 1;   // optex_cdf_fused (include/optex.h, ABI 9)
+
 static long pick_chunk(long n, int ncols, int n_cu) {
     // aim for >= 8 blocks per CU in flight; chunks are multiples of 1024 elements (256 threads x float4)
     const long want_blocks = 8L * n_cu;
@@ -805,15 +952,32 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
     a.shist = (smn_given && smx_given) ? shist_given : nullptr;   // (they go with the given source range)
     a.vec_t = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0;
     a.vec_s = aligned16(source) && lds % 4 == 0 && sss % 4 == 0;
+    const int vec = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0 && aligned16(out) && ldo % 4 == 0 && oss % 4 == 0;
+    const int blocks_y = (a.chunks_t == 1 && a.chunks_s == 1) ? 1 : a.chunks_t + a.chunks_s;
+    // algorithmic bytes of the histogram stage: every DISTINCT column once — a shared source (src_n_seg == 1) is binned with
+    // each target segment's range (n_seg blocks per channel re-read it through L2) but comes from HBM once — and the 3 KB LUT
+    // per column that reaches HBM (the histograms, CDFs and edges stay in LDS)
+    const double hist_bytes = 4.0 * ((double)nt * ncols + (double)ns * C * src_n_seg) + 3.0 * 4 * kBins * ncols;
+    if (cdf_fused_enabled && blocks_y == 1 && vec && a.vec_t && nt % 4 == 0 && nt <= 16384 && ns <= 65536) {
+        // the whole matcher in one launch, the column in registers: the target is read once and written once (KC_CDF_FUSED)
+        ProfScope prof(KC_CDF_FUSED, st, 0.0, 8.0 * (double)nt * ncols + 4.0 * (double)ns * C * src_n_seg);
+        const int per = (int)((nt / 4 + 255) / 256);
+        const dim3 grid(ncols), blk(256);
+        if (per <= 2) hipLaunchKernelGGL(cdf_fused_kernel<2>, grid, blk, 0, st, a, out, ldo, oss);
+        else if (per <= 4) hipLaunchKernelGGL(cdf_fused_kernel<4>, grid, blk, 0, st, a, out, ldo, oss);
+        else if (per <= 6) hipLaunchKernelGGL(cdf_fused_kernel<6>, grid, blk, 0, st, a, out, ldo, oss);
+        else if (per <= 8) hipLaunchKernelGGL(cdf_fused_kernel<8>, grid, blk, 0, st, a, out, ldo, oss);
+        else if (per <= 10) hipLaunchKernelGGL(cdf_fused_kernel<10>, grid, blk, 0, st, a, out, ldo, oss);
+        else if (per <= 12) hipLaunchKernelGGL(cdf_fused_kernel<12>, grid, blk, 0, st, a, out, ldo, oss);
+        else if (per <= 14) hipLaunchKernelGGL(cdf_fused_kernel<14>, grid, blk, 0, st, a, out, ldo, oss);
+        else hipLaunchKernelGGL(cdf_fused_kernel<16>, grid, blk, 0, st, a, out, ldo, oss);
+        return check_launch("cdf_fused_kernel");
+    }
     {
-        // algorithmic bytes: every DISTINCT column once — a shared source (src_n_seg == 1) is binned with each target
-        // segment's range (n_seg blocks per channel re-read it through L2) but comes from HBM once; + the LUT's tables
-        ProfScope prof(KC_HIST, st, 0.0, 4.0 * ((double)nt * ncols + (double)ns * C * src_n_seg) + (2.0 * 4 + 3.0 * 4) * kBins * ncols);
-        const int blocks_y = (a.chunks_t == 1 && a.chunks_s == 1) ? 1 : a.chunks_t + a.chunks_s;
+        ProfScope prof(KC_HIST, st, 0.0, hist_bytes);
         hipLaunchKernelGGL(cdf_hist_lut_kernel, dim3(ncols, blocks_y), dim3(256), 0, st, a);
     }
     if ((rc = check_launch("cdf_hist_lut_kernel"))) return rc;
-    const int vec = aligned16(target) && ldt % 4 == 0 && tss % 4 == 0 && aligned16(out) && ldo % 4 == 0 && oss % 4 == 0;
     long chunk = pick_chunk(nt, ncols, n_cu);
     const int chunks = (int)((nt + chunk - 1) / chunk);
     ProfScope prof(KC_APPLY, st, 0.0, 8.0 * (double)nt * ncols);
@@ -832,6 +996,12 @@ int minmax_fold_parts(const float* pmn, const float* pmx, int parts, int C, int 
 }  // namespace optex
 
 using namespace optex;
+
+extern "C" int optex_cdf_fused(int on) {
+    const int old = cdf_fused_enabled;
+    cdf_fused_enabled = on != 0;
+    return old;
+}
 
 extern "C" int optex_col_minmax(const float* x, long ld, long seg_stride, long n, int C, int n_seg, float* mn, float* mx,
                                 void* stream) {

@@ -59,7 +59,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
 // Off by default: no events, no overhead.  Classes are stable ABI (optex_prof_class_name).
 enum KClass { KC_GEMM = 0, KC_MINMAX, KC_HIST, KC_LUT, KC_APPLY, KC_SORT, KC_SORT_MATCH, KC_MEAN, KC_GRAM, KC_COVFIN,
-              KC_ROTGEN, KC_INTERP, KC_SORT_FALLBACK, KC_GLUE, KC_SMALL_GEMM, KC_CHOL, KC_NS_INIT, KC_NORMALS, KC_COUNT };
+              KC_ROTGEN, KC_INTERP, KC_SORT_FALLBACK, KC_GLUE, KC_SMALL_GEMM, KC_CHOL, KC_NS_INIT, KC_NORMALS, KC_CDF_FUSED, KC_COUNT };
 struct ProfScope {
     int cls;
     hipStream_t st;

@@ -320,3 +320,9 @@ def gemm_spare_cus(spare: int) -> int:
     of another stream — the rotation generator, an RCCL broadcast — then never makes one of its workgroups wait for a CU).
     Returns the previous value."""
     return int(_lib.load().optex_gemm_spare_cus(int(spare)))
+
+
+def cdf_fused(on: bool) -> bool:
+    """The cdf matcher as ONE kernel that keeps each column in registers (include/optex.h, optex_cdf_fused; default on) or as the
+    two-kernel pipeline (histograms + LUT, then the interpolation).  The same bits either way.  Returns the previous setting."""
+    return bool(_lib.load().optex_cdf_fused(1 if on else 0))

@@ -46,8 +46,10 @@ def main():
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=str, default="gemm,cdf,sort,linear,glue,loop")
+    ap.add_argument("--cdf_fused", type=int, default=1, help="0: the two-kernel cdf pipeline (optex_cdf_fused)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    ops.cdf_fused(bool(args.cdf_fused))
     S, C, n, ns = args.S, args.C, args.n, args.ns
     only = set(args.only.split(","))
     g = torch.Generator(device=dev).manual_seed(0)
@@ -55,7 +57,7 @@ def main():
     style = torch.randn((1, C, ns), device=dev, generator=g).clamp_min_(0) * 1.5
     R32, Rt32 = rotation.rotations(C, 4, dev, rng=np.random.RandomState(0))
     y = torch.empty_like(x)
-    tag = f"S{S}_C{C}_n{n}"
+    tag = f"S{S}_C{C}_n{n}" + ("" if args.cdf_fused else "_twokernel")
 
     def timed(fn, reps=args.reps, warm=3):
         for _ in range(warm):

@@ -16,7 +16,7 @@ import csv
 import json
 import re
 
-CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("gemm_rs_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"),
+CLASS_OF = [("gemm_tn_kernel", "gemm_tn"), ("gemm16_cm_kernel", "gemm_tn"), ("gemm_rs_kernel", "gemm_tn"), ("cdf_apply_kernel", "cdf_apply"), ("cdf_fused_kernel", "cdf_match"),
             ("col_hist_kernel", "col_hist"), ("cdf_hist_lut_kernel", "col_hist"), ("col_minmax_kernel", "col_minmax"), ("cdf_lut_kernel", "cdf_lut"),
             ("mt_accept_kernel", "legacy_normals"), ("normals_emit_kernel", "legacy_normals"), ("gram_tri_kernel", "gram"),
             ("chol_inv2_kernel", "chol_inv"),

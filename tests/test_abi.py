@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/optex.h but not exported by liboptex_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes and header disagree"
-    assert lib.optex_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.optex_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_size_helpers_need_no_gpu():

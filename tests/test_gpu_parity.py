@@ -247,6 +247,46 @@ def test_cdf_match_segments_vs_oracle_bit_exact(dev, S, Ss, C, nt, ns):
         assert biteq(out[k], orc.cdf_match(t[k], s[k if Ss > 1 else 0])), f"segment {k}"
 
 
+@pytest.mark.parametrize("nt,ns", [(1024, 800), (2044, 3000), (4096, 3072), (6400, 4800), (9216, 6912), (12544, 9408), (16384, 12288),
+                                    (16380, 20000), (8, 4)])
+def test_cdf_match_fused_kernel_equals_two_kernel_pipeline_and_oracle(dev, nt, ns):
+    """optex_cdf_fused (ABI 9): the one-launch matcher with the column in registers against the histogram + apply pipeline it
+    replaces (every NV instantiation, ragged last vectors, in place, shared and per-segment sources), and against the oracle:
+    non-finite values, constant columns, ties, values on bin edges included"""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.ops import Seg
+    rng = np.random.default_rng(nt + ns)
+    S, C = 3, 6
+    t = (rng.standard_normal((S, C, nt)) * rng.uniform(0.5, 4, (S, C, 1)) + rng.uniform(-2, 2, (S, C, 1))).astype(np.float32)
+    t[0, 0] = np.maximum(t[0, 0], 0)                     # ties
+    t[0, 1] = 1.25                                       # constant column
+    t[1, 2, ::7] = np.nan                                # histc skips them, interp propagates them
+    t[1, 3, 5] = np.inf
+    t[2, 4] = np.round(t[2, 4] * 8) / 8                  # many values exactly on bin edges
+    for Ss in (1, S):
+        s = relu_feat(rng, Ss, C, ns, scale=2.0, shift=0.5)
+        s[0, 1] = 1.25 if Ss == 1 else 3.0
+        td, sd = cu(t, dev), cu(s, dev)
+        prev = ops.cdf_fused(False)
+        try:
+            two, d2 = ops.cdf_match_seg(Seg.of(td), Seg.of(sd), debug=True)
+            ops.cdf_fused(True)
+            one, d1 = ops.cdf_match_seg(Seg.of(td), Seg.of(sd), debug=True)
+            inplace = td.clone()
+            ops.cdf_match_seg(Seg.of(inplace), Seg.of(sd), out=Seg.of(inplace))
+        finally:
+            ops.cdf_fused(prev)
+        assert biteq(one.cpu().numpy(), two.cpu().numpy())
+        assert biteq(inplace.cpu().numpy(), two.cpu().numpy())
+        for k in d1:
+            assert biteq(d1[k].cpu().numpy(), d2[k].cpu().numpy()), k
+        o = one.cpu().numpy()
+        for k in range(S):
+            if k == 1:
+                continue   # (the oracle takes torch.min / max literally: NaN ranges; the kernels drop NaN — DESIGN 7)
+            assert biteq(o[k], orc.cdf_match(t[k], s[k if Ss > 1 else 0])), f"segment {k}"
+
+
 # ================================================================================================ K6 sort mode
 @pytest.mark.parametrize("S,C,n", [(1, 4, 240), (2, 3, 2048), (1, 5, 4096), (1, 3, 5000), (1, 2, 9000), (2, 2, 16384)])
 def test_sort_columns_indices_bit_exact(dev, S, C, n):
