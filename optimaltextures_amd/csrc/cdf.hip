@@ -185,7 +185,11 @@ __device__ __forceinline__ void hist_add(unsigned* h, float v, float lo, float h
     int pos = (int)(FAST ? div_by(a, range, inv) : __fdiv_rn(a, range));   // (the conversion saturates; NaN -> 0)
     pos = pos > kBins - 1 ? kBins - 1 : pos;
     pos = pos < 0 ? 0 : pos;
+#ifdef CDF_PROBE_NOATOMIC   // scripts/cdf_probe.hip: the binning arithmetic without its LDS atomic
+    if (pos == 0x7fffffff) atomicAdd(&h[pos & 255], inc);
+#else
     atomicAdd(&h[pos], inc);
+#endif
 }
 
 template <bool FAST>
@@ -198,7 +202,7 @@ __device__ __forceinline__ void hist_add4(unsigned* h, const float4 v, float hl,
 
 // Four 16-byte loads in flight per thread (round 5: the plain loop compiled to load -> s_waitcnt vmcnt(0) -> 4 atomics, ONE
 // kilobyte in flight per wavefront — 32 KB per CU where ~60 KB cover the HBM round trip at full rate)
-template <bool FAST>
+template <bool FAST, int NT = 256>
 __device__ __forceinline__ void hist_chunk_t(unsigned* h, const float* __restrict__ p, long beg, long end, int vec, float hl, float hu,
                                              float range, float inv) {
     const int tid = threadIdx.x;
@@ -206,24 +210,25 @@ __device__ __forceinline__ void hist_chunk_t(unsigned* h, const float* __restric
         const long nv = (end - beg) / 4;
         const float4* p4 = reinterpret_cast<const float4*>(p + beg);
         long i = tid;
-        for (; i + 768 < nv; i += 1024) {
-            const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+        for (; i + 3 * NT < nv; i += 4 * NT) {
+            const float4 v0 = p4[i], v1 = p4[i + NT], v2 = p4[i + 2 * NT], v3 = p4[i + 3 * NT];
             hist_add4<FAST>(h, v0, hl, hu, range, inv);
             hist_add4<FAST>(h, v1, hl, hu, range, inv);
             hist_add4<FAST>(h, v2, hl, hu, range, inv);
             hist_add4<FAST>(h, v3, hl, hu, range, inv);
         }
-        for (; i < nv; i += 256) hist_add4<FAST>(h, p4[i], hl, hu, range, inv);
-        for (long j = beg + nv * 4 + tid; j < end; j += 256) hist_add<FAST>(h, p[j], hl, hu, range, inv);
+        for (; i < nv; i += NT) hist_add4<FAST>(h, p4[i], hl, hu, range, inv);
+        for (long j = beg + nv * 4 + tid; j < end; j += NT) hist_add<FAST>(h, p[j], hl, hu, range, inv);
     } else {
-        for (long i = beg + tid; i < end; i += 256) hist_add<FAST>(h, p[i], hl, hu, range, inv);
+        for (long i = beg + tid; i < end; i += NT) hist_add<FAST>(h, p[i], hl, hu, range, inv);
     }
 }
 // (the reciprocal is taken once per call: one division per thread and chunk)
+template <int NT = 256>
 __device__ __forceinline__ void hist_chunk(unsigned* h, const float* __restrict__ p, long beg, long end, int vec, float hl, float hu,
                                            float range) {
-    if (div_by_ok(range)) hist_chunk_t<true>(h, p, beg, end, vec, hl, hu, range, __fdiv_rn(1.0f, range));
-    else hist_chunk_t<false>(h, p, beg, end, vec, hl, hu, range, 0.f);
+    if (div_by_ok(range)) hist_chunk_t<true, NT>(h, p, beg, end, vec, hl, hu, range, __fdiv_rn(1.0f, range));
+    else hist_chunk_t<false, NT>(h, p, beg, end, vec, hl, hu, range, 0.f);
 }
 
 // grid = (columns, chunks).  lohi_seg_div: the (lo, hi) of column (seg, c) is read at [(seg / lohi_seg_div), c] so that a
@@ -268,9 +273,14 @@ struct LutShared {
 // thread i returns with remapped_cdf[i] in `r_out` and the slope of bin i in `slope_out`, S.edges / S.rm hold the tables.
 __device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned hs, float lo, float hi, float* __restrict__ l,
                                            float* __restrict__ d, float& r_out, float& slope_out) {
-    const int i = threadIdx.x, lane = i & 63, w = i >> 6;
-    S.rt[i] = ht;
-    S.rs[i] = hs;
+    // (a 512-thread workgroup calls it with all its threads: thread 256 + i mirrors thread i's arithmetic — it must pass the
+    // barriers anyway — and only the lower half writes)
+    const int i = threadIdx.x & (kBins - 1), lane = i & 63, w = i >> 6;
+    const bool wr = threadIdx.x < kBins;
+    if (wr) {
+        S.rt[i] = ht;
+        S.rs[i] = hs;
+    }
     // inclusive scan: inside the wavefront by lane shifts, the three wave totals through LDS (one barrier; the Hillis-Steele
     // scan over LDS this replaces had sixteen); integer, hence exact and equal to torch's fp32 cumsum while totals < 2^24
     unsigned ct = ht, cs = hs;
@@ -282,7 +292,7 @@ __device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned h
             cs += b;
         }
     }
-    if (lane == 63) {
+    if (lane == 63 && wr) {
         S.ct[w] = ct;
         S.cs[w] = cs;
     }
@@ -303,7 +313,7 @@ __device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned h
     if (tot_t >= (1u << 24) || tot_s >= (1u << 24)) {
         // beyond 2^24 the reference's sequential fp32 cumsum rounds: replay it literally
         __syncthreads();
-        if (i == 0) {
+        if (threadIdx.x == 0) {
             float a = 0.f, b = 0.f;
             for (int k = 0; k < kBins; k++) {
                 a = a + (float)S.rt[k];
@@ -320,27 +330,29 @@ __device__ __forceinline__ void lut_column(LutShared& S, unsigned ht, unsigned h
         __syncthreads();
     }
     const float step = __fdiv_rn(hi - lo, (float)kBins);
-    S.tcdf[i] = __fdiv_rn(ft, tl);
-    S.scdf[i] = __fdiv_rn(fs, sl);
-    S.edges[i] = linspace_edge(lo, hi, step, i + 1);
+    if (wr) {
+        S.tcdf[i] = __fdiv_rn(ft, tl);
+        S.scdf[i] = __fdiv_rn(fs, sl);
+        S.edges[i] = linspace_edge(lo, hi, step, i + 1);
+    }
     __syncthreads();
     // remapped_cdf = interp(target_cdf, source_cdf, bin_edges)   histmatch.py:67
     const float x = S.tcdf[i];
     int idx = lower_bound_f(S.scdf, kBins, x);
     idx = idx > kBins - 1 ? kBins - 1 : idx;
     const float r = interp_eval(x, idx, S.scdf, S.edges, kBins);
-    S.rm[i] = r;
+    if (wr) S.rm[i] = r;
     __syncthreads();
     const int nxt = (i + 1 > kBins - 1) ? kBins - 1 : i + 1;
     const float slope = __fdiv_rn(S.rm[nxt] - S.rm[i], S.edges[nxt] - S.edges[i]);
     r_out = r;
     slope_out = slope;
-    if (l) {
+    if (l && wr) {
         l[i] = S.edges[i];
         l[kBins + i] = r;
         l[2 * kBins + i] = slope;
     }
-    if (d) {
+    if (d && wr) {
         if (i == 0) {
             d[0] = lo;
             d[1] = hi;
@@ -496,12 +508,15 @@ __device__ __forceinline__ float lut_apply(float x, float lo, float range256, co
         idx = (t >= 0.f) ? ((t < 255.f) ? (int)t : 255) : 0;
     }
     float4 q = T[idx];
+    // (the common case is evaluated straight from the candidate's entry, all four components consumed at once: with the
+    // evaluation behind the fix-up branch the compiler split the entry into four separate LDS reads)
+    float f = __fadd_rn(__fmul_rn(q.w, x - q.y), q.z);
     if (q.x >= x || (idx < kBins - 1 && !(q.y >= x))) {   // rare: the candidate is a neighbour of the bin (or x is NaN)
         while (idx > 0 && T[idx].x >= x) idx--;
         while (idx < kBins - 1 && !(T[idx].y >= x)) idx++;
         q = T[idx];
+        f = __fadd_rn(__fmul_rn(q.w, x - q.y), q.z);
     }
-    float f = __fadd_rn(__fmul_rn(q.w, x - q.y), q.z);
     if (!finite_f(f)) {
         const float4 q2 = T[(idx + 1 > kBins - 1) ? kBins - 1 : idx + 1];
         const float f2 = __fadd_rn(__fmul_rn(q.w, x - q2.y), q2.z);
@@ -509,12 +524,50 @@ __device__ __forceinline__ float lut_apply(float x, float lo, float range256, co
     }
     return f;
 }
+// candidate bin of x from the histogram formula (only seeds the search)
+__device__ __forceinline__ int lut_guess(float x, float lo, float range256) {
+    int idx = 0;
+    if (range256 > 0.f) {
+        const float t = (x - lo) * range256;
+        idx = (t >= 0.f) ? ((t < 255.f) ? (int)t : 255) : 0;
+    }
+    return idx;
+}
+// the rest of lut_apply given the candidate's entry q
+__device__ __forceinline__ float lut_finish(float x, int idx, float4 q, const float4* T) {
+    float f = __fadd_rn(__fmul_rn(q.w, x - q.y), q.z);
+    if (q.x >= x || (idx < kBins - 1 && !(q.y >= x))) {   // rare: the candidate is a neighbour of the bin (or x is NaN)
+        while (idx > 0 && T[idx].x >= x) idx--;
+        while (idx < kBins - 1 && !(T[idx].y >= x)) idx++;
+        q = T[idx];
+        f = __fadd_rn(__fmul_rn(q.w, x - q.y), q.z);
+    }
+    if (!finite_f(f)) {
+        const float4 q2 = T[(idx + 1 > kBins - 1) ? kBins - 1 : idx + 1];
+        const float f2 = __fadd_rn(__fmul_rn(q.w, x - q2.y), q2.z);
+        f = finite_f(f2) ? f2 : q.z;
+    }
+    return f;
+}
+// Four elements: their four candidate entries as four ds_read_b128 issued back to back.  Written in C++ the compiler splits
+// every entry into three or four narrower reads (it wants q.x / q.y early for the branch and sinks the rest): 13 LDS
+// instructions per 16-byte vector instead of four, on the pipe that bounds this step.
+typedef float lut_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 lut_apply4(const float4 v, float lo, float range256, const float4* T) {
+    const int i0 = lut_guess(v.x, lo, range256), i1 = lut_guess(v.y, lo, range256), i2 = lut_guess(v.z, lo, range256),
+              i3 = lut_guess(v.w, lo, range256);
+    const unsigned base = (unsigned)(uintptr_t)T;   // (the low half of a flat LDS address is the LDS byte offset)
+    lut_f4 q0, q1, q2, q3;
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+        : "v"(base + 16u * (unsigned)i0), "v"(base + 16u * (unsigned)i1), "v"(base + 16u * (unsigned)i2), "v"(base + 16u * (unsigned)i3)
+        : "memory");
     float4 r;
-    r.x = lut_apply(v.x, lo, range256, T);
-    r.y = lut_apply(v.y, lo, range256, T);
-    r.z = lut_apply(v.z, lo, range256, T);
-    r.w = lut_apply(v.w, lo, range256, T);
+    r.x = lut_finish(v.x, i0, make_float4(q0[0], q0[1], q0[2], q0[3]), T);
+    r.y = lut_finish(v.y, i1, make_float4(q1[0], q1[1], q1[2], q1[3]), T);
+    r.z = lut_finish(v.z, i2, make_float4(q2[0], q2[1], q2[2], q2[3]), T);
+    r.w = lut_finish(v.w, i3, make_float4(q3[0], q3[1], q3[2], q3[3]), T);
     return r;
 }
 
@@ -555,56 +608,43 @@ __global__ __launch_bounds__(256) void cdf_apply_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------ K2 + K3 in one launch
 // Range, both histograms, the LUT AND the interpolation of a column in one workgroup that keeps the column in REGISTERS
-// (round 5): a column of the hot loop is at most 16384 values = 16 float4 per thread, so the target is read from HBM once —
-// binned from the registers, matched from the registers, stored — instead of once by the histogram kernel and once more by the
-// apply kernel: 8 bytes per element instead of 12 (24 instead of 28 per element and iteration of the whole cdf step), three
-// launches per iteration instead of four, and all NV loads of a thread are in flight together.  The LUT never leaves the CU.
+// (round 5): a column of the hot loop is at most 16384 values, so the target is read from HBM once — binned from the
+// registers, matched from the registers, stored — instead of once by the histogram kernel and once more by the apply kernel:
+// 8 bytes per element instead of 12 (24 instead of 28 per element and iteration of the whole cdf step), three launches per
+// iteration instead of four.  The LUT never leaves the CU.  One workgroup per column, several columns per CU in different
+// phases (what the arithmetic of one hides is the memory phase of another; profiles/r05_cdf_probe.md):
+//   * a PERSISTENT, double-buffered variant (next column requested before the current one is worked on, two workgroups per CU)
+//     was built and measured slower — 640 against 514 us at 16384 values per column: a column's phases are a serial chain of
+//     ~20 us on one workgroup, and two workgroups per CU overlap less than four;
+//   * the range comes in as ONE pair per column (a.lo / a.hi, or the source range joined with a folded pair): folding the GEMM's
+//     per-tile partials in here — 256 strided 4-byte reads per column, each a 64-byte line — cost 100 us per launch at 64
+//     textures per step (617 against 514 us); the fold is a 12 us kernel of its own (minmax_from_parts_kernel, coalesced).
 // Same arithmetic as cdf_hist_lut_kernel + cdf_apply_kernel, statement for statement (they stay: columns longer than 16384
-// values or cut into chunks, unaligned rows).  grid = (columns); nt % 4 == 0, nt <= 1024 NV, rows 16-byte aligned.
-// (registers: NV float4 of column + ~40; columns up to 10240 values run five workgroups per CU, the longest four)
-template <int NV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NV <= 2 ? 8 : (NV <= 10 ? 5 : 4)))) void cdf_fused_kernel(HistLutArgs a, float* __restrict__ out, long ldo, long oss) {
-    const int col = blockIdx.x, seg = col / a.C, c = col % a.C, tid = threadIdx.x;
-    __shared__ unsigned sh[4][kBins];
-    __shared__ float slo[4], shi[4];
+// values or cut into chunks, unaligned rows).  grid = (columns); nt % 4 == 0, nt <= 4 NT NV, rows 16-byte aligned.
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void cdf_fused_kernel(HistLutArgs a, float* __restrict__ out, long ldo, long oss) {
+    constexpr int NW = NT / 64;
+    const int col = blockIdx.x, seg = col / a.C, c = col - seg * a.C, tid = threadIdx.x;
+    __shared__ unsigned sh[NW][kBins];
     __shared__ LutShared S;
     __shared__ float4 T[kBins];
-    const float* pt = a.t + (size_t)seg * a.tss + (size_t)c * a.ldt;
-    const float4* p4 = reinterpret_cast<const float4*>(pt);
     const int nv = (int)(a.nt / 4);
+    const float4* p4 = reinterpret_cast<const float4*>(a.t + (size_t)seg * a.tss + (size_t)c * a.ldt);
     float4 v[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++)
-        if (tid + 256 * k < nv) v[k] = p4[tid + 256 * k];
-    for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
-    float lo, hi;
+        if (tid + NT * k < nv) v[k] = p4[tid + NT * k];
+    for (int i = tid; i < NW * kBins; i += NT) (&sh[0][0])[i] = 0u;
+    float lo = a.lo[col], hi = a.hi[col];
     bool src_range = false;
-    if (a.pmn) {
-        lo = INFINITY;
-        hi = -INFINITY;
-        const float* pa = a.pmn + (size_t)seg * a.parts * a.C + c;
-        const float* pb = a.pmx + (size_t)seg * a.parts * a.C + c;
-        for (int p = tid; p < a.parts; p += 256) {
-            lo = fminf(lo, pa[(size_t)p * a.C]);
-            hi = fmaxf(hi, pb[(size_t)p * a.C]);
-        }
-        lo = wave_min(lo);
-        hi = wave_max(hi);
-        if ((tid & 63) == 0) {
-            slo[tid >> 6] = lo;
-            shi[tid >> 6] = hi;
-        }
-        __syncthreads();
+    {  // the target's range (folded from the GEMM's partials) joined with the source's   histmatch.py:52-53
         const int oc = ((a.src_n_seg == 1) ? 0 : seg) * a.C + c;
         const float smn = a.smn[oc], smx = a.smx[oc];
-        lo = fminf(fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])), smn);   // histmatch.py:52-53
-        hi = fmaxf(fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3])), smx);
+        lo = fminf(lo, smn);
+        hi = fmaxf(hi, smx);
         src_range = a.shist != nullptr && lo == smn && hi == smx;   // uniform over the block
-    } else {
-        lo = a.lo[col];
-        hi = a.hi[col];
-        __syncthreads();
     }
+    __syncthreads();
     float hl = lo, hu = hi;
     if (hl == hu) {  // torch.histc widens an empty range
         hl -= 1.0f;
@@ -612,45 +652,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NV <= 2 ? 8
     }
     const float range = hu - hl;
     unsigned* h = sh[tid >> 6];
+#ifdef CDF_PROBE_NOHIST
+    if (range == 12345.f) {
+#else
     if (div_by_ok(range)) {
+#endif
         const float inv = __fdiv_rn(1.0f, range);
 #pragma unroll
         for (int k = 0; k < NV; k++)
-            if (tid + 256 * k < nv) hist_add4<true>(h, v[k], hl, hu, range, inv);
+            if (tid + NT * k < nv) hist_add4<true>(h, v[k], hl, hu, range, inv);
     } else {
 #pragma unroll
         for (int k = 0; k < NV; k++)
-            if (tid + 256 * k < nv) hist_add4<false>(h, v[k], hl, hu, range, 0.f);
+            if (tid + NT * k < nv) hist_add4<false>(h, v[k], hl, hu, range, 0.f);
     }
     __syncthreads();
-    const unsigned ht = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    const int bin = tid & (kBins - 1);
+    unsigned ht = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) ht += sh[k][bin];
     unsigned hs;
     if (src_range) {
-        hs = a.shist[((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * kBins + tid];
+        hs = a.shist[((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * kBins + bin];
     } else {
         const float* ps = a.s + (size_t)((a.src_n_seg == 1) ? 0 : seg) * a.sss + (size_t)c * a.lds;
         __syncthreads();
-        for (int i = tid; i < 4 * kBins; i += 256) (&sh[0][0])[i] = 0u;
+        for (int i = tid; i < NW * kBins; i += NT) (&sh[0][0])[i] = 0u;
         __syncthreads();
-        hist_chunk(h, ps, 0, a.ns, a.vec_s, hl, hu, range);
+        // (a plain loop, one load in flight: inside optex_ot_loop this branch runs for the few columns whose range sticks out of
+        // the style's; unrolled like hist_chunk its registers were the kernel's)
+        if (a.vec_s) {
+            const float4* s4 = reinterpret_cast<const float4*>(ps);
+            const int nvs = (int)(a.ns / 4);
+#pragma unroll 1
+            for (int i = tid; i < nvs; i += NT) hist_add4<false>(h, s4[i], hl, hu, range, 0.f);
+#pragma unroll 1
+            for (long j = 4L * nvs + tid; j < a.ns; j += NT) hist_add<false>(h, ps[j], hl, hu, range);
+        } else {
+#pragma unroll 1
+            for (long j = tid; j < a.ns; j += NT) hist_add<false>(h, ps[j], hl, hu, range);
+        }
         __syncthreads();
-        hs = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+        hs = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) hs += sh[k][bin];
     }
-    if (tid == 0) {
+    if (tid == 0) {   // (the joint range: the two-kernel pipeline leaves it here too)
         a.lo[col] = lo;
         a.hi[col] = hi;
     }
     float* d = a.dbg ? a.dbg + (size_t)col * (2 + 4 * kBins) : nullptr;
     float r, slope;
+#ifdef CDF_PROBE_NOLUT
+    r = (float)(ht + hs);
+    slope = 1.f;
+    if (tid < kBins) S.edges[tid] = lo + (float)(tid + 1) * (hi - lo) * (1.f / 256.f);
+    __syncthreads();
+#else
     lut_column(S, ht, hs, lo, hi, nullptr, d, r, slope);
-    T[tid] = make_float4(tid > 0 ? S.edges[tid - 1] : __uint_as_float(0x7fc00000u), S.edges[tid], r, slope);
+#endif
+    if (tid < kBins) T[tid] = make_float4(tid > 0 ? S.edges[tid - 1] : __uint_as_float(0x7fc00000u), S.edges[tid], r, slope);
     __syncthreads();
     const float arange = hi - lo;
     const float range256 = (arange > 0.f) ? 256.f / arange : 0.f;
     float4* o4 = reinterpret_cast<float4*>(out + (size_t)seg * oss + (size_t)c * ldo);
 #pragma unroll
-    for (int k = 0; k < NV; k++)
-        if (tid + 256 * k < nv) o4[tid + 256 * k] = lut_apply4(v[k], lo, range256, T);
+    for (int k = 0; k < NV; k++) {
+#ifdef CDF_PROBE_NOAPPLY
+        if (tid + NT * k < nv) o4[tid + NT * k] = v[k] * T[k].z;
+#else
+        if (tid + NT * k < nv) o4[tid + NT * k] = lut_apply4(v[k], lo, range256, T);
+#endif
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ any bin count
@@ -910,6 +983,32 @@ int col_hist_launch(const float* x, long ld, long ss, long n, int C, int n_seg, 
     return launch_hist(x, ld, ss, n, C, n_seg, n_seg, lo, hi, hist, st);
 }
 
+#ifndef CDF_FUSED_NT_BIG
+#define CDF_FUSED_NT_BIG 256   // threads per column above 8192 values: 256 measured faster than 512 at every size (503 against 588 us at
+                               // 16384 values, scripts/cdf_probe.hip builds both)
+#endif
+template <int NV, int NT>
+static int launch_fused_t(const HistLutArgs& a, float* out, long ldo, long oss, int ncols, hipStream_t st) {
+    hipLaunchKernelGGL((cdf_fused_kernel<NV, NT>), dim3((unsigned)ncols), dim3(NT), 0, st, a, out, ldo, oss);
+    return check_launch("cdf_fused_kernel");
+}
+
+static int launch_fused(const HistLutArgs& a, float* out, long ldo, long oss, int ncols, hipStream_t st) {
+    const long nv = a.nt / 4;
+    if (nv <= 2048 || CDF_FUSED_NT_BIG == 256) {
+        const int per = (int)((nv + 255) / 256);
+        if (per <= 2) return launch_fused_t<2, 256>(a, out, ldo, oss, ncols, st);
+        if (per <= 4) return launch_fused_t<4, 256>(a, out, ldo, oss, ncols, st);
+        if (per <= 6) return launch_fused_t<6, 256>(a, out, ldo, oss, ncols, st);
+        if (per <= 8) return launch_fused_t<8, 256>(a, out, ldo, oss, ncols, st);
+        if (per <= 12) return launch_fused_t<12, 256>(a, out, ldo, oss, ncols, st);
+        return launch_fused_t<16, 256>(a, out, ldo, oss, ncols, st);
+    }
+    const int per = (int)((nv + 511) / 512);
+    if (per <= 6) return launch_fused_t<6, 512>(a, out, ldo, oss, ncols, st);
+    return launch_fused_t<8, 512>(a, out, ldo, oss, ncols, st);
+}
+
 int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,
                    int src_n_seg, int C, int n_seg, float* out, long ldo, long oss, void* ws, float* dbg,
                    hipStream_t st) {
@@ -960,18 +1059,12 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
     const double hist_bytes = 4.0 * ((double)nt * ncols + (double)ns * C * src_n_seg) + 3.0 * 4 * kBins * ncols;
     if (cdf_fused_enabled && blocks_y == 1 && vec && a.vec_t && nt % 4 == 0 && nt <= 16384 && ns <= 65536) {
         // the whole matcher in one launch, the column in registers: the target is read once and written once (KC_CDF_FUSED)
+        if (tmn_parts) {   // the target's own range, one pair per column (joined with the source's inside the kernel)
+            if ((rc = minmax_fold_parts(tmn_parts, tmx_parts, parts, C, ncols, w.lo, w.hi, st))) return rc;
+            a.pmn = a.pmx = nullptr;
+        }   // (without partials w.lo / w.hi hold the joint range already: joining it with the source's range again changes nothing)
         ProfScope prof(KC_CDF_FUSED, st, 0.0, 8.0 * (double)nt * ncols + 4.0 * (double)ns * C * src_n_seg);
-        const int per = (int)((nt / 4 + 255) / 256);
-        const dim3 grid(ncols), blk(256);
-        if (per <= 2) hipLaunchKernelGGL(cdf_fused_kernel<2>, grid, blk, 0, st, a, out, ldo, oss);
-        else if (per <= 4) hipLaunchKernelGGL(cdf_fused_kernel<4>, grid, blk, 0, st, a, out, ldo, oss);
-        else if (per <= 6) hipLaunchKernelGGL(cdf_fused_kernel<6>, grid, blk, 0, st, a, out, ldo, oss);
-        else if (per <= 8) hipLaunchKernelGGL(cdf_fused_kernel<8>, grid, blk, 0, st, a, out, ldo, oss);
-        else if (per <= 10) hipLaunchKernelGGL(cdf_fused_kernel<10>, grid, blk, 0, st, a, out, ldo, oss);
-        else if (per <= 12) hipLaunchKernelGGL(cdf_fused_kernel<12>, grid, blk, 0, st, a, out, ldo, oss);
-        else if (per <= 14) hipLaunchKernelGGL(cdf_fused_kernel<14>, grid, blk, 0, st, a, out, ldo, oss);
-        else hipLaunchKernelGGL(cdf_fused_kernel<16>, grid, blk, 0, st, a, out, ldo, oss);
-        return check_launch("cdf_fused_kernel");
+        return launch_fused(a, out, ldo, oss, ncols, st);
     }
     {
         ProfScope prof(KC_HIST, st, 0.0, hist_bytes);

@@ -1,0 +1,115 @@
+// Diagnostic (not part of the library): where the fused cdf matcher (cdf_fused_kernel, csrc/cdf.hip) spends a column.  The same
+// kernel is built with one phase knocked out at a time (-DCDF_PROBE_...), beside a plain copy with the same access pattern
+// (one workgroup per 64 KB column, NV 16-byte loads per thread in flight).  [64 x 256] gaussian columns, the joint range is
+// the source's (+-4.5 sigma: what the hot loop sees), the shared source histogram is given.  Built by scripts/Makefile.
+//   scripts/cdf_probe_<variant>.bin [n] [reps]
+#include "../optimaltextures_amd/csrc/cdf.hip"
+
+#include <vector>
+
+__global__ void fill_gauss(float* x, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned a = (unsigned)i * 2654435761u ^ seed, b = (unsigned)(i >> 32) * 40503u + 0x9e3779b9u + seed;
+        a ^= a >> 16; a *= 0x85ebca6bu; a ^= a >> 13; a *= 0xc2b2ae35u; a ^= a >> 16;
+        b ^= a; b ^= b >> 16; b *= 0x85ebca6bu; b ^= b >> 13; b *= 0xc2b2ae35u; b ^= b >> 16;
+        const float u1 = ((a >> 8) + 1) * (1.0f / 16777217.0f), u2 = (b >> 8) * (1.0f / 16777216.0f);
+        x[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void copy_columns(const float* __restrict__ x, float* __restrict__ y, long n) {
+    const float4* p = reinterpret_cast<const float4*>(x + (size_t)blockIdx.x * n);
+    float4* o = reinterpret_cast<float4*>(y + (size_t)blockIdx.x * n);
+    const int nv = (int)(n / 4), tid = threadIdx.x;
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (tid + 256 * k < nv) v[k] = p[tid + 256 * k];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (tid + 256 * k < nv) o[tid + 256 * k] = v[k];
+}
+
+__global__ void spread_parts(const float* mn, const float* mx, float* pmn, float* pmx, int C, int parts, int ncols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over [n_seg][parts][C]
+    if (i >= ncols * parts) return;
+    const int c = i % C, seg = i / (C * parts);
+    pmn[i] = mn[seg * C + c];
+    pmx[i] = mx[seg * C + c];
+}
+
+int main(int argc, char** argv) {
+    const long n = argc > 1 ? atol(argv[1]) : 16384;
+    const int reps = argc > 2 ? atoi(argv[2]) : 10;
+    const int C = 256, S = 64, ncols = C * S;
+    const long ns = n * 3 / 4;
+    float *x, *y, *src, *smn, *smx, *pmn, *pmx, *cmn, *cmx;
+    const int parts = (int)(n / 64);   // what the R-stationary rotation GEMM leaves: one pair per 64-pixel tile
+    unsigned* shist;
+    void* ws;
+    const size_t wsb = optex_cdf_ws_bytes(C, S);
+    hipMalloc(&x, (size_t)ncols * n * 4); hipMalloc(&y, (size_t)ncols * n * 4); hipMalloc(&src, (size_t)C * ns * 4);
+    hipMalloc(&smn, C * 4); hipMalloc(&smx, C * 4); hipMalloc(&pmn, (size_t)ncols * parts * 4); hipMalloc(&pmx, (size_t)ncols * parts * 4); hipMalloc(&cmn, ncols * 4); hipMalloc(&cmx, ncols * 4);
+    hipMalloc(&shist, (size_t)C * 256 * 4); hipMalloc(&ws, wsb);
+    fill_gauss<<<4096, 256>>>(x, (size_t)ncols * n, 1u);
+    fill_gauss<<<1024, 256>>>(src, (size_t)C * ns, 7u);
+    std::vector<float> lo(C, -4.5f), hi(C, 4.5f);
+    hipMemcpy(smn, lo.data(), C * 4, hipMemcpyHostToDevice);
+    hipMemcpy(smx, hi.data(), C * 4, hipMemcpyHostToDevice);
+    optex::col_minmax_launch(x, n, (long)C * n, n, C, S, cmn, cmx, 0);
+    spread_parts<<<(ncols * parts + 255) / 256, 256>>>(cmn, cmx, pmn, pmx, C, parts, ncols);
+    optex::col_hist_launch(src, ns, (long)C * ns, ns, C, 1, smn, smx, shist, 0);
+    optex::cdf_ws_clear(ws, C, S, 0);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timed = [&](const char* what, auto fn, double bytes) {
+        float best = 1e30f, ms;
+        for (int it = 0; it < reps + 2; it++) {
+            hipEventRecord(e0, 0);
+            fn();
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, e0, e1);
+            if (it > 1 && ms < best) best = ms;
+        }
+        printf("%-44s n = %5ld  %8.1f us  %6.2f TB/s on %4.1f B/element  (%.3f of 8 TB/s)\n", what, n, best * 1e3, bytes / (best * 1e9),
+               bytes / ((double)ncols * n), bytes / (best * 1e9) / 8.0);
+    };
+#ifndef CDF_PROBE_NAME
+#define CDF_PROBE_NAME "cdf_fused_kernel (shipping)"
+#endif
+    timed(CDF_PROBE_NAME, [&] {
+        optex::cdf_match_parts_impl(x, n, (long)C * n, n, src, ns, (long)C * ns, ns, 1, C, S, y, n, (long)C * n, ws, nullptr, pmn, pmx, parts, 0,
+                                    smn, smx, true, shist);
+    }, 8.0 * ncols * n);
+    // the same launch as the hot loop meets it: in place, on a map the previous kernel has just written (1 GB of dirty lines)
+    {
+        float best = 1e30f, ms;
+        for (int it = 0; it < reps + 2; it++) {
+            hipMemcpyAsync(y, x, (size_t)ncols * n * 4, hipMemcpyDeviceToDevice, 0);
+            hipEventRecord(e0, 0);
+            optex::cdf_match_parts_impl(y, n, (long)C * n, n, src, ns, (long)C * ns, ns, 1, C, S, y, n, (long)C * n, ws, nullptr, pmn, pmx, parts, 0,
+                                        smn, smx, true, shist);
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, e0, e1);
+            if (it > 1 && ms < best) best = ms;
+        }
+        printf("%-44s n = %5ld  %8.1f us  (incl. the fold of the partials)\n", "  ... in place, behind a kernel that wrote the map", n, best * 1e3);
+    }
+    timed("copy, one workgroup per column, NV loads", [&] {
+        const int per = (int)((n / 4 + 255) / 256);
+        if (per <= 4) copy_columns<4><<<ncols, 256>>>(x, y, n);
+        else if (per <= 8) copy_columns<8><<<ncols, 256>>>(x, y, n);
+        else if (per <= 12) copy_columns<12><<<ncols, 256>>>(x, y, n);
+        else copy_columns<16><<<ncols, 256>>>(x, y, n);
+    }, 8.0 * ncols * n);
+    std::vector<float> got(n);
+    hipMemcpy(got.data(), y + 5 * n, n * 4, hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (float v : got) sum += v;
+    printf("  (checksum of column 5: %.6f; last error: %s)\n", sum, optex_last_error());
+    return 0;
+}
