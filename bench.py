@@ -299,7 +299,10 @@ def main():
             rng.prefetch(sched)
         ahead.clear()
         nxt = rot(q_next)
-        nxt.prefetch(sched)
+        # (fed, not prefetched: the next group's draws are released one pass at a time at the start of this step's decode phases
+        # — beside convolutions; all at once they ran beside the first OT loops, whose persistent GEMM then had to leave a CU free)
+        nxt.begin_feed(sched)
+        model.rng_next = nxt
         ahead[(id(model), q_next)] = nxt
         return rng
 

@@ -520,7 +520,9 @@ static inline bool rs_aligned16(const void* p) { return (reinterpret_cast<uintpt
 bool gemm_rs_supported(const GemmArgs& a, int n_cu) {
     if (a.epi || a.sym) return false;
     if (a.bsub && a.bsub_ss != 0 && a.at_ss == 0) return false;  // a workgroup keeps one matrix AND one centring vector
-    if (a.bsub && a.M > 192) return false;  // (four row tiles per wave + the centring ring spill: the LDS-tiled kernel takes these)
+    // centring with four row tiles per wave (M > 192): built for K = 256 exactly and for K <= 192; the ragged 192 < K < 256
+    // instantiation spills 32 registers (the LDS-tiled kernel takes those)
+    if (a.bsub && a.M > 192 && a.K > 192 && a.K != 256) return false;
     if (a.M <= 64 || a.M > 256 || a.K < 64 || a.K > 256) return false;
     if (a.n % RS_BN != 0 || a.n <= 0) return false;
     if (!rs_aligned16(a.B) || a.ldb % 4 != 0 || a.b_ss % 4 != 0) return false;
@@ -550,12 +552,11 @@ static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
         return OPTEX_E_UNSUPPORTED;
     }
     if (a.bsub) {
-        if constexpr (MT <= 3) {
+        // (round 5: with the matrix in accumulation registers the centring ring fits beside four row tiles too)
+        if ((MT == 4 && KS == 64) && a.K == 4 * KS)
+            hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2, 1, (MT == 4 && KS == 64)>), grid, dim3(256), 0, st, ra);
+        else
             hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2>), grid, dim3(256), 0, st, ra);
-        } else {  // four row tiles per wave leave no registers for the centring ring: never launched silently as a no-op
-            set_error("gemm_rs_kernel: bsub with M > 192 is not built (gemm_rs_supported says so)");
-            return OPTEX_E_UNSUPPORTED;
-        }
     } else if (a.badd || a.content) {
         if ((MT == 4 && KS == 64) && a.K == 4 * KS)
             hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1, 1, (MT == 4 && KS == 64)>), grid, dim3(256), 0, st, ra);

@@ -330,6 +330,8 @@ class OptimalTexture(torch.nn.Module):
         # whole batch, optex.py:168-170), or a list of one RandomState per texture (independent=True): every
         # texture then draws its own rotations — the batch equals B separate runs of the reference, seed for seed
         self.rng = None
+        self.rng_next = None          # the NEXT call's DeviceNormals (begin_feed() done): fed during this call's codec phases
+        self.gemm_spare_cus = "auto"   # CUs the persistent rotation GEMM leaves free: "auto" (0 unless generator kernels may run beside an OT loop) or an int
 
     # -- optex.py:45-79, channel-major
     def _needs_resize(self, hw, size: int) -> bool:
@@ -502,6 +504,7 @@ class OptimalTexture(torch.nn.Module):
         # with PCA: all fits of the call up front too (one batched eigensolve per layer width instead of one call per fit)
         sides = (self.prefetch_style_sides(pastiche.shape[-2:], styles, content)
                  if (self.style_sync is not None or self.use_pca) else None)
+        ungated = False
         if isinstance(self.rng, rotation.DeviceNormals):
             # device-side numpy stream(s): the draws of the whole call go out now, on the generator's side stream — they
             # depend on nothing but the stream state and the (known) sizes, so they run beside the convolutions.  A caller
@@ -510,6 +513,31 @@ class OptimalTexture(torch.nn.Module):
             schedule = self.rotation_schedule(sides)
             if not self.rng.covers(schedule):
                 self.rng.prefetch(schedule)
+                ungated = True   # ~12 ms of generator kernels start now, beside whatever this call does first
+        # a caller that knows its NEXT job hands over that job's generator (`rng_next`, begin_feed() done): its draws are released
+        # one (pass, layer) at a time at the start of this call's codec phases — beside convolutions, never beside an OT loop
+        nxt = getattr(self, "rng_next", None)
+        nxt = nxt if isinstance(nxt, rotation.DeviceNormals) and nxt.feeding() else None
+
+        def feed_next():
+            if nxt is not None and nxt.feeding():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(pastiche.device))
+                nxt.feed_one(after=ev)
+
+        # The persistent rotation GEMM wants every CU whole (include/optex.h, optex_gemm_spare_cus): one CU is left out of its grid
+        # only when the generator's one-workgroup kernels may run beside an OT loop of this call — the un-gated prefetch above.
+        # Draws that were fed during the previous call's codec phases (and this call's feeding of the next one) run beside
+        # convolutions, which share a CU without harm.
+        spare = (1 if ungated else 0) if self.gemm_spare_cus == "auto" else int(self.gemm_spare_cus)
+        prev_spare = ops.gemm_spare_cus(spare) if pastiche.is_cuda else None
+        try:
+            return self._forward_passes(pastiche, styles, content, verbose, on_layer, sides, nxt, feed_next)
+        finally:
+            if prev_spare is not None:
+                ops.gemm_spare_cus(prev_spare)
+
+    def _forward_passes(self, pastiche, styles, content, verbose, on_layer, sides, nxt, feed_next):
         for p in range(self.passes):
             if verbose:
                 print(f"Pass {p}, size {self.sizes[p]}")
@@ -549,6 +577,7 @@ class OptimalTexture(torch.nn.Module):
                         cf = cf.expand(b, k, h * w).contiguous()
                     x = ops.ot_loop_pca(self.hist_mode, x.contiguous(), style_eigvs[li], style_eigvs[li].t().contiguous(),
                                         style_features[li], R32, Rt32, content=cf, strength=strength)
+                    feed_next()
                     pastiche = decoder.decode(x.view(b, -1, h, w))
                     if on_layer is not None:
                         replaced = on_layer(p, li, pastiche)
@@ -564,12 +593,16 @@ class OptimalTexture(torch.nn.Module):
                                   pooled=not self.independent, rng=self.rng, fuse_rotations=self.fuse_rotations)
                 if self.use_pca:
                     x = unproject_cm(x, style_eigvs[li].t().contiguous())
+                feed_next()
                 pastiche = decoder.decode(x.view(b, -1, h, w))
                 if on_layer is not None:
                     replaced = on_layer(p, li, pastiche)
                     if replaced is not None:
                         pastiche = replaced
 
+        if nxt is not None:
+            nxt.finish_feed()
+            self.rng_next = None
         if self.color_transfer is not None:
             assert content is not None, "Color transfer requires content image"
             target_hls = rgb_to_hls(content)

@@ -155,13 +155,61 @@ class DeviceNormals:
         """the pending prefetch is exactly the head of `schedule` (non-empty entries): a forward() call that finds its
         schedule covered does not draw again — the draws were enqueued ahead of time, e.g. during the previous step"""
         want = [(int(n), int(c)) for n, c in schedule if c > 0]
-        have = self.pending()
+        have = self.pending() + list(getattr(self, "_feed", []) or [])
         return len(have) > 0 and have == want[:len(have)]
 
     def drop_pending(self):
         """forget prefetched rotations (a forward() that raised midway, a schedule that changed): the stream stays where the
         draws left it — the dropped values are consumed, exactly as if someone had asked for them and thrown them away"""
         self._queue.clear()
+        self._feed = []
+
+    # ---- a schedule fed piece by piece: the draws of the NEXT call released one (pass, layer) at a time by the CURRENT call, each
+    # at the start of one of its VGG codec phases (driver.OptimalTexture.forward, `rng_next`).  All at once (prefetch) the
+    # generator's ~12 ms of one compute unit run beside whatever the main stream does then — at 8 textures per step that is the
+    # first OT loops, whose persistent rotation GEMM wants every CU whole (include/optex.h, optex_gemm_spare_cus).  The
+    # convolutions do not mind sharing a CU with the generator's one workgroup, the GEMM does.
+    def begin_feed(self, schedule):
+        """start a fed schedule: nothing is enqueued yet; feed_one() releases the entries in order, finish_feed() the rest"""
+        self.drop_pending()
+        self._feed = [(int(n), int(c)) for n, c in schedule if c > 0]
+        self._fed_bytes = 0
+
+    def feeding(self) -> bool:
+        return bool(getattr(self, "_feed", None))
+
+    def feed_one(self, after=None):
+        """enqueue the next entry of the fed schedule on the generator's stream, behind `after` (an event of the caller's
+        stream: the point in ITS timeline from which the draw may run).  Returns False when nothing is left to feed."""
+        if not self.feeding():
+            return False
+        N, count = self._feed[0]
+        self._fed_bytes += 8 * self.n * count * N * N
+        if self._fed_bytes > self.PREFETCH_BYTES:   # (the rest is drawn when it is asked for, like prefetch() does)
+            self._feed = []
+            return False
+        self._feed.pop(0)
+        if self.stream is not None and after is not None:
+            self.stream.wait_event(after)
+        self._enqueue(N, count)
+        return True
+
+    def finish_feed(self):
+        """enqueue whatever of the fed schedule has not been released yet (a call with fewer codec phases than the next one
+        has entries, a caller that stops feeding)"""
+        while self.feed_one():
+            pass
+
+    def _enqueue(self, N, count):
+        normals, ev = self.draw(count * ops.rotation_normals(N))
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                R = self._rotations_from(normals, N, count)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+        else:
+            R = self._rotations_from(normals, N, count)
+        self._queue.append((N, count, R, ev))
 
     def prefetch(self, schedule):
         """schedule: [(N, count), ...] in the order the rotations will be asked for.  Draws AND Householder accumulations go
@@ -176,21 +224,15 @@ class DeviceNormals:
                 held += 8 * self.n * count * N * N
                 if held > self.PREFETCH_BYTES:
                     break
-                normals, ev = self.draw(count * ops.rotation_normals(N))
-                if self.stream is not None:
-                    with torch.cuda.stream(self.stream):
-                        R = self._rotations_from(normals, N, count)
-                        ev = torch.cuda.Event()
-                        ev.record(self.stream)
-                else:
-                    R = self._rotations_from(normals, N, count)
-                self._queue.append((N, count, R, ev))
+                self._enqueue(N, count)
 
     def rotations(self, N: int, count: int):
         if N is None or not np.isscalar(N) or N <= 1 or N != int(N):
             raise ValueError("Dimension of rotation must be specified,\n and must be a scalar greater than 1.")
         N, count = int(N), int(count)
         cur = torch.cuda.current_stream(self.device)
+        if not self._queue and self.feeding():
+            self.feed_one()   # asked for before its release point came: draw it now (same stream position, same values)
         if self._queue:
             qn, qc, R, ev = self._queue[0]
             if (qn, qc) == (N, count):

@@ -71,16 +71,35 @@ def main():
             host_a = time.perf_counter() - t0
             torch.cuda.synchronize()
             aht = time.perf_counter() - t0
+
+            # ... the next group's draws FED during this step's decode phases instead (bench.py's default from round 5's second half)
+            def run_fed(n, q0):
+                sched = tex.rotation_schedule()
+                rng = otdist.rotation_stream(0, q0, dev)
+                rng.prefetch(sched)
+                for q in range(q0, q0 + n):
+                    nxt = otdist.rotation_stream(0, q + 1, dev)
+                    nxt.begin_feed(sched)
+                    tex.rng, tex.rng_next = rng, nxt
+                    tex.forward(otdist.texture_noise(q * B, B, (3, 512, 512), dev), [style])
+                    rng = nxt
+
+            run_fed(2, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_fed(steps, 2)
+            torch.cuda.synchronize()
+            fedt = time.perf_counter() - t0
             # device stream with one workgroup of the persistent GEMM on EVERY CU (spare = 0: what rounds 3-4 did)
             from optimaltextures_amd import ops as _ops
-            prev = _ops.gemm_spare_cus(0)
+            tex.gemm_spare_cus = 0
             run_dev(1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             run_dev(steps)
             torch.cuda.synchronize()
             dev0 = time.perf_counter() - t0
-            _ops.gemm_spare_cus(prev)
+            tex.gemm_spare_cus = "auto"
             # the same steps with every rotation batch of the call served from a device-side cache
             cache, own = {}, rotation.rotations
 
@@ -111,6 +130,7 @@ def main():
               f"device stream {B * steps / devt:7.1f} textures/s ({1e3 * devt / steps:6.1f} ms/step, host enqueue {1e3 * host_d / steps:6.1f} ms) | "
               f"device stream, no spare CU in the GEMM grid {B * steps / dev0:7.1f} textures/s ({1e3 * dev0 / steps:6.1f} ms/step) | "
               f"device stream a step ahead {B * steps / aht:7.1f} textures/s ({1e3 * aht / steps:6.1f} ms/step, host enqueue {1e3 * host_a / steps:6.1f} ms) | "
+              f"device stream fed during the previous step's decode phases {B * steps / fedt:7.1f} textures/s ({1e3 * fedt / steps:6.1f} ms/step) | "
               f"cached rotations {B * steps / gpu:7.1f} textures/s ({1e3 * gpu / steps:6.1f} ms/step, host enqueue {1e3 * host_c / steps:6.1f} ms) | "
               f"drawing one step's 1.71 M normals on the host: {1e3 * draw:.1f} ms")
 

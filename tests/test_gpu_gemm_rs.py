@@ -91,7 +91,8 @@ def test_rs_gemm_nonfinite_rows_beyond_k_do_not_leak(dev):
     assert np.isfinite(got[0]).all() and biteq(got[0], orc.gemm_tn(At, x[0]))
 
 
-@pytest.mark.parametrize("M,K", [(181, 181), (165, 165), (181, 256), (192, 192), (84, 84), (100, 128)])
+@pytest.mark.parametrize("M,K", [(181, 181), (165, 165), (181, 256), (192, 192), (84, 84), (100, 128), (256, 256), (256, 181), (224, 160),
+                                 (256, 224)])
 def test_rs_gemm_centred_operand_bit_exact(dev, M, K):
     """the apply step of the linear modes at PCA ranks (histmatch.py:27/34/42,44: T @ (hist_t - mu_t) + mu_s): per-segment
     operators, per-segment centring vector and bias, content blend — one subtraction per operand element, one rounding"""

@@ -1225,6 +1225,53 @@ def test_device_stream_drawn_a_step_ahead_is_the_same_stream(dev):
     assert np.array_equal(sa[1], sd[1]) and sa[2:4] == sd[2:4]
 
 
+def test_device_stream_fed_during_the_previous_call_is_the_same_stream(dev):
+    """DeviceNormals.begin_feed / feed_one / finish_feed + OptimalTexture.rng_next: the NEXT call's draws released one (pass, layer)
+    at a time at the start of THIS call's decode phases.  Same stream, same rotations, same images as two calls that each
+    prefetch their own schedule; a fed stream that is asked before its release point draws on demand; auto spare-CU policy"""
+    from optimaltextures_amd import ops
+    from optimaltextures_amd.driver import OptimalTexture
+    from optimaltextures_amd.rotation import DeviceNormals
+    tex = OptimalTexture(size=128, iters=60, passes=2, hist_mode="cdf", layers=(3, 2), no_pca=True, independent=True).to(dev).eval()
+    sched = tex.rotation_schedule()
+    want = [(int(n), int(k)) for n, k in sched]
+    a, b = DeviceNormals(77, dev), DeviceNormals(77, dev)
+    a.begin_feed(sched)
+    assert a.feeding() and a.covers(sched) and a.pending() == []
+    ev = torch.cuda.Event()
+    ev.record()
+    assert a.feed_one(after=ev) and a.pending() == want[:1] and a.covers(sched)
+    r0 = a.rotations(*want[0])          # released: taken from the queue
+    r1 = a.rotations(*want[1])          # not released yet: drawn on demand, same stream position
+    a.finish_feed()
+    assert a.pending() == want[2:] and not a.feeding()
+    rest = [a.rotations(n, k) for n, k in want[2:]]
+    for got, (n, k) in zip([r0, r1] + rest, want):
+        ref = b.rotations(n, k)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    # two calls back to back, the second one's generator fed during the first
+    g = torch.Generator().manual_seed(0)
+    x0, x1 = (torch.rand(1, 3, 128, 128, generator=g).to(dev) for _ in range(2))
+    style = torch.rand(1, 3, 96, 128, generator=g).to(dev)
+    with torch.inference_mode():
+        tex.rng = DeviceNormals(5, dev)
+        ref0 = tex.forward(x0.clone(), [style])
+        tex.rng = DeviceNormals(6, dev)
+        ref1 = tex.forward(x1.clone(), [style])
+        first, second = DeviceNormals(5, dev), DeviceNormals(6, dev)
+        first.prefetch(sched)
+        second.begin_feed(sched)
+        tex.rng, tex.rng_next = first, second
+        prev = ops.gemm_spare_cus(1)
+        out0 = tex.forward(x0.clone(), [style])
+        assert ops.gemm_spare_cus(prev) == 1            # forward() restores the process-wide setting it found
+        assert tex.rng_next is None and not second.feeding() and second.pending() == want and second.covers(sched)
+        tex.rng = second
+        out1 = tex.forward(x1.clone(), [style])
+    assert torch.equal(out0, ref0) and torch.equal(out1, ref1)
+
+
 def test_forward_with_device_rotation_stream_equals_host_stream(dev):
     """OptimalTexture.forward with its rotations drawn on the GPU (prefetched for the whole call on a side stream) against the
     same call with the numpy stream on the host: same seeds -> same rotations to 1 ulp of fp32 -> the same image to fp32
