@@ -1250,15 +1250,12 @@ def test_device_stream_fed_during_the_previous_call_is_the_same_stream(dev):
         ref = b.rotations(n, k)
         torch.cuda.synchronize()
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-    # two calls back to back, the second one's generator fed during the first
+    # two calls back to back, the second one's generator fed during the first (MIOpen's convolutions are not reproducible run
+    # to run — scripts/miopen_determinism_probe.py — so the images are not compared: the streams' positions are)
     g = torch.Generator().manual_seed(0)
     x0, x1 = (torch.rand(1, 3, 128, 128, generator=g).to(dev) for _ in range(2))
     style = torch.rand(1, 3, 96, 128, generator=g).to(dev)
     with torch.inference_mode():
-        tex.rng = DeviceNormals(5, dev)
-        ref0 = tex.forward(x0.clone(), [style])
-        tex.rng = DeviceNormals(6, dev)
-        ref1 = tex.forward(x1.clone(), [style])
         first, second = DeviceNormals(5, dev), DeviceNormals(6, dev)
         first.prefetch(sched)
         second.begin_feed(sched)
@@ -1269,7 +1266,13 @@ def test_device_stream_fed_during_the_previous_call_is_the_same_stream(dev):
         assert tex.rng_next is None and not second.feeding() and second.pending() == want and second.covers(sched)
         tex.rng = second
         out1 = tex.forward(x1.clone(), [style])
-    assert torch.equal(out0, ref0) and torch.equal(out1, ref1)
+    assert bool(torch.isfinite(out0).all()) and bool(torch.isfinite(out1).all()) and not second.pending()
+    for seed, used in ((5, first), (6, second)):
+        ref = DeviceNormals(seed, dev)
+        for n, k in want:
+            ref.rotations(n, k)
+        sa, sb = ref.state(0), used.state(0)
+        assert np.array_equal(sa[1], sb[1]) and sa[2:4] == sb[2:4]
 
 
 def test_forward_with_device_rotation_stream_equals_host_stream(dev):
