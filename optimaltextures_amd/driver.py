@@ -529,7 +529,9 @@ class OptimalTexture(torch.nn.Module):
         # only when the generator's one-workgroup kernels may run beside an OT loop of this call — the un-gated prefetch above.
         # Draws that were fed during the previous call's codec phases (and this call's feeding of the next one) run beside
         # convolutions, which share a CU without harm.
-        spare = (1 if ungated else 0) if self.gemm_spare_cus == "auto" else int(self.gemm_spare_cus)
+        # (with a style_sync hook the later passes' RCCL broadcasts may still be in flight during the first loops: one CU stays free)
+        crowded = ungated or (self.style_sync is not None and sides is not None)
+        spare = (1 if crowded else 0) if self.gemm_spare_cus == "auto" else int(self.gemm_spare_cus)
         prev_spare = ops.gemm_spare_cus(spare) if pastiche.is_cuda else None
         try:
             return self._forward_passes(pastiche, styles, content, verbose, on_layer, sides, nxt, feed_next)
