@@ -92,6 +92,9 @@ constexpr int RS_DEPTH_DB = RS_DEPTH_DB_VALUE;
 #ifndef RS_DB
 #define RS_DB 1        // 0: probe build without the double-buffered accumulators
 #endif
+#ifndef RS_DB_RAGGED
+#define RS_DB_RAGGED 0
+#endif
 #ifndef RS_SPLIT_LOAD
 #define RS_SPLIT_LOAD 0   // in-loop refill as two 8-byte halves: measured SLOWER (111.6 against 115.1 TFLOP/s, profiles/r05_gemm_probes.md)
 #endif
@@ -566,15 +569,18 @@ static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
         // un-projected feature maps (C = 256, C = 128): K fills the instantiation exactly
         constexpr bool HOT = (MT == 4 && KS == 64) || (MT == 2 && KS == 32);
         const bool kfull = HOT && a.K == 4 * KS;
+        // double-buffered accumulators for the ragged (PCA-rank) instantiations too (-DRS_DB_RAGGED=1 probe build): three row
+        // tiles per wave and 48 k-steps leave the registers for it (M, K <= 192)
+        constexpr bool DBR = RS_DB_RAGGED != 0 && RS_DB != 0 && MT == 3 && KS == 48;
         if (a.rowstat == 1) {
             if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0, 1, HOT, HOT && MT == 4 && RS_DB != 0>), grid, dim3(256), 0, st, ra);
-            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0>), grid, dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 1, 0, 1, false, DBR>), grid, dim3(256), 0, st, ra);
         } else if (a.rowstat == 2) {
             if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0, 1, HOT, HOT && MT == 4 && RS_DB != 0>), grid, dim3(256), 0, st, ra);
-            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0>), grid, dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 2, 0, 1, false, DBR>), grid, dim3(256), 0, st, ra);
         } else {
             if (kfull) hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0, 1, HOT, HOT && MT == 4 && RS_DB != 0>), grid, dim3(256), 0, st, ra);
-            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0>), grid, dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 0, 1, false, DBR>), grid, dim3(256), 0, st, ra);
         }
     }
     return check_launch("gemm_rs_kernel");
