@@ -1,7 +1,9 @@
-// cdf.hip — K2a/K2b/K2c/K3: the reference's `cdf` histogram matching (histmatch.py:49-92) as four streaming
-// kernels over channel-major columns.  All of them are HBM-bound (0 flop/B); what matters is that every
-// column is read in whole 16-byte vectors and that the per-column state (256-bin histogram, 3 KB LUT) lives
-// in LDS.  Algorithmic bytes per (pixel, channel): min/max 4, histogram 4, apply 8.
+// cdf.hip — K2a/K2b/K2c/K3: the reference's `cdf` histogram matching (histmatch.py:49-92) over channel-major columns: as
+// ONE kernel that keeps a column in registers (cdf_fused_kernel, round 5: columns of up to 16384 values, every batched call of
+// the hot loop: 8 bytes per element) or as streaming kernels (min/max, histograms + LUT, apply: longer, chunked or unaligned
+// columns: min/max 4, histogram 4, apply 8 bytes per element).  0 flop/B: what matters is that every column is
+// read in whole 16-byte vectors, that enough of them are in flight, and that the per-column state (256-bin histograms, the
+// LUT as 16-byte entries) lives in LDS.
 //
 // Exactness rules (so that the result is bit-identical to the reference on identical inputs):
 //   * bin = trunc((x - lo) * 256 / (hi - lo)) with a true IEEE division, x == hi -> bin 255, lo == hi -> [lo-1, hi+1]
