@@ -21,8 +21,14 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# MIOpen's find mode (torch.backends.cudnn.benchmark) times EVERY applicable solver of a convolution once per shape, its naive
+# reference kernel included — 0.3-1 s per launch at the bench's shapes, ~200 s of the warm-up step (profiles/r05a conv instance
+# lists).  The naive solver never wins; it is taken out of the search (an environment variable of MIOpen, set before torch loads
+# it; the timed steps are the same: 208.97 against 208.92 textures/s, 159 against 207 s of wall clock for a 3-step run).
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -354,7 +360,10 @@ def main():
                    "rotation_sharing": f"one sequence per rotation group of {B} textures (= one rank's step), seeded by the group's global number",
                    "rotation_stream": "numpy RandomState gaussian stream, drawn on the host" if args.host_rng else
                                       ("numpy RandomState gaussian stream advanced on the GPU (optex_legacy_normals)" +
-                                       ("" if args.no_rng_ahead else ", group q + 1 drawn on the side stream while group q is synthesised"))},
+                                       ("" if args.no_rng_ahead else ", group q + 1 drawn on the side stream during the decode phases of group q")),
+                   "miopen_find": ("off (heuristics / find-db)" if args.no_miopen_find else
+                                   "on (torch.backends.cudnn.benchmark), naive reference solver excluded from the search "
+                                   f"(MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD={os.environ.get('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD')})")},
     }
     traffic, traffic_source = pmc_traffic()
     if traffic_source:
