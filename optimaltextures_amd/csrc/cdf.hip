@@ -1006,9 +1006,14 @@ static int launch_fused(const HistLutArgs& a, float* out, long ldo, long oss, in
         if (per <= 12) return launch_fused_t<12, 256>(a, out, ldo, oss, ncols, st);
         return launch_fused_t<16, 256>(a, out, ldo, oss, ncols, st);
     }
+#if CDF_FUSED_NT_BIG == 512   // (probe build only: the library has no 512-thread instantiation)
     const int per = (int)((nv + 511) / 512);
     if (per <= 6) return launch_fused_t<6, 512>(a, out, ldo, oss, ncols, st);
     return launch_fused_t<8, 512>(a, out, ldo, oss, ncols, st);
+#else
+    set_error("cdf_fused_kernel: no instantiation for %ld values per column", a.nt);
+    return OPTEX_E_UNSUPPORTED;
+#endif
 }
 
 int cdf_match_impl(const float* target, long ldt, long tss, long nt, const float* source, long lds, long sss, long ns,

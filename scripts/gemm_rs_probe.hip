@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 5 ? atoi(argv[5]) : 20;
     const bool old = argc > 6 && atoi(argv[6]) == 1;
     const int mode = argc > 7 ? atoi(argv[7]) : 0;  // feature-map data: 0 = gaussian, 1 = zeros, 2 = max(gaussian, 0)
+    const int rowstat = argc > 8 ? atoi(argv[8]) : 0;  // 1 = min / max, 2 = sums of the output rows in the epilogue (GemmArgs::rowstat)
     optex::gemm_rs_enabled = !old;
     optex::gemm_rs_force = !old;
     std::vector<float> hb((size_t)S * K * n), ha((size_t)K * M);
@@ -33,6 +34,11 @@ int main(int argc, char** argv) {
     optex::GemmArgs a{};
     a.At = A; a.lda = M; a.at_ss = 0; a.B = B; a.ldb = n; a.b_ss = (long)K * n; a.O = O; a.ldo = n; a.o_ss = (long)M * n;
     a.M = M; a.K = K; a.n = n; a.n_seg = S; a.alpha = 1.f; a.prof_cls = optex::KC_GEMM;
+    float *ra = nullptr, *rb = nullptr;
+    if (rowstat) {
+        (void)hipMalloc(&ra, (size_t)S * (n / 64) * M * 4); (void)hipMalloc(&rb, (size_t)S * (n / 64) * M * 4);
+        a.rowstat = rowstat; a.rs_a = ra; a.rs_b = rb;
+    }
     const int CM = OPTEX_CHANNEL_MAJOR;
     const int n_cu = optex::device_cu_count();
     if (!optex::gemm_rs_supported(a, n_cu)) { printf("shape not supported\n"); return 1; }
@@ -51,6 +57,12 @@ int main(int argc, char** argv) {
     double chk = 0;
     for (float v : ho) chk += v;
     const double us = 1e3 * ms / reps, tf = 2.0 * M * K * (double)n * S / (us * 1e6);
+    if (rowstat) {
+        std::vector<float> hr((size_t)M * 4);
+        (void)hipMemcpy(hr.data(), ra, hr.size() * 4, hipMemcpyDeviceToHost);
+        for (float v : hr) chk += v;
+        printf("[rowstat %d] ", rowstat);
+    }
     printf("%s ring %d%s, %s data: S=%d n=%ld M=%d K=%d  %.1f us  %.1f TFLOP/s  (%.3f of 157.3)  checksum %.6f\n", old ? "LDS-tiled kernel," : "R-stationary kernel,", RS_DEPTH_VALUE,
 #ifdef RS_PROBE_NOLOAD
            " NOLOAD",
