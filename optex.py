@@ -10,12 +10,17 @@ import argparse
 import os
 from time import time
 
-import numpy as np
-import torch
+# --cudnn_benchmark (MIOpen's find mode) times every applicable solver of a convolution once per shape, its naive reference
+# kernel included (0.3-1 s per launch at 512^2 batches); that solver never wins and is taken out of the search.  Without the flag
+# nothing is searched and this does nothing.  (An environment variable of MIOpen: set before torch loads the library.)
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 
-from optimaltextures_amd import dist as otdist
-from optimaltextures_amd.driver import OptimalTexture
-from optimaltextures_amd.util import load_styles, maybe_load_content, save_image
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from optimaltextures_amd import dist as otdist  # noqa: E402
+from optimaltextures_amd.driver import OptimalTexture  # noqa: E402
+from optimaltextures_amd.util import load_styles, maybe_load_content, save_image  # noqa: E402
 
 
 def required_length(nmin, nmax):
