@@ -275,7 +275,7 @@ def main():
     style = synthetic_style(device)
     tex = make_texturizer(args.hist_mode, device, no_pca=not args.pca)
     if world > 1:
-        tex.style_sync = otdist.StyleSync(device)  # pass p's style side is encoded by rank p mod N and broadcast from there (RCCL), one payload per pass
+        tex.style_sync = otdist.StyleSync(device, spread=True)  # pass p's style side is encoded by rank p mod N and broadcast from there (RCCL), one payload per pass
     # Seeding rule of sharded jobs (optimaltextures_amd/dist.py): textures are numbered globally; the B textures of one step of
     # one rank are ROTATION GROUP q = step * world + rank (textures q*B .. q*B + B - 1): their noise comes from per-texture
     # generators, their shared rotation sequence from RandomState(rotation_seed(seed, q)) — texture i is the same image

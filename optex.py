@@ -130,7 +130,7 @@ def main(argv=None):
             for enc, dec in zip(texturizer.encoders, texturizer.decoders):
                 print(f"relu{enc.depth}_1 weights: encoder {enc.weights} | decoder {dec.weights}")
         if world > 1:
-            texturizer.style_sync = otdist.StyleSync(device)
+            texturizer.style_sync = otdist.StyleSync(device, spread=True)
 
         t = time()
         pastiche = texturizer.forward(pastiche, styles, content, verbose=rank == 0)

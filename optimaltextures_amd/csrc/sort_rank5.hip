@@ -1,0 +1,611 @@
+// sort_rank5.hip — rank_match5_kernel: the exact 1-D transport match (north-star addition; specification =
+// oracle/optex_oracle.c orc_sort_match) with a ranking step built for FEWER LDS OPERATIONS PER KEY than rank_match4_kernel
+// (sort_rank4.hip), whose 8-slot window costs every key a place write and four 8-byte reads at random addresses.
+//
+// Round 6: the bucket table is over-provisioned — FOUR fine buckets per key, 8-bit counters packed four to a
+// 32-bit word — so that with the histogram-equalised map ~78 % of the keys are ALONE in their bucket.  For those keys
+//      rank = group_start[bucket >> 2] + (sum of the counter bytes below bucket & 3 in the word)
+// is final: no place write, no window read.  Only keys that share a bucket (~22 %) are written to the (then dead) counter
+// array and compared with their bucket mates; exact ties go through a short list ordered by (totalOrder key, pixel).
+//
+// Per key on the LDS pipe: bucket-table read, returning count atomic, counter word, group start, source pick = 5 random-address
+// operations on all lanes (rank_match4_kernel: table, atomic, start entry, place, 4 window reads, pick = 9) + place / mate reads
+// on a fifth of the lanes + coalesced 16-byte passes (zero, scan, group starts, source staging).
+//
+// Layout: ONE persistent workgroup per CU (the counters alone are 4 bytes per key: 64 KiB at 16384 keys, + 32 KiB of group
+// starts), 16 wavefronts at a 128-register budget; the next column's keys are requested as soon as this column's are dead
+// (behind the mate compare) and arrive while the source is staged, picked and stored.  A workgroup walks the columns
+// blockIdx.x, + gridDim.x, ...: with C = gridDim.x = 256 it sees the SAME channel of every texture, i.e. the same sorted source
+// column every time (L2-resident).
+//
+// Everything the kernel cannot take is flagged for the radix sweep behind it (sort.hip), like rank_match4_kernel does:
+// non-finite keys, a bucket of 256 or more keys (8-bit counter), more than R5_TCAP keys with an equal partner.
+#include "sort_common.h"
+#include <type_traits>
+
+namespace optex {
+
+constexpr int R5_TCAP = 256;               // keys with an equal partner, per column
+constexpr uint32_t R5_TAG = 0x80000000u;   // rank register: index into the tie list, result pending
+constexpr uint32_t R5_INF = 0x7f800000u;
+
+typedef float r5_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned r5_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned r5_v2u __attribute__((ext_vector_type(2)));
+typedef float r5_v2f __attribute__((ext_vector_type(2)));
+#define R5_LDS(T, off) (*reinterpret_cast<__attribute__((address_space(3))) T*>((uint32_t)(off)))
+
+template <int ITEMS, int NT>
+struct R5 {
+    static constexpr int CAP = ITEMS * NT;
+    static constexpr int QR = (ITEMS + 3) / 4;        // 16-byte rows of counter words per thread
+    static constexpr int NWRD = 4 * NT * QR;          // counter words, four 8-bit buckets each (>= CAP)
+    static constexpr int NBK = 4 * NWRD;              // fine buckets
+    static constexpr int WMIN = 4;                    // fine buckets every coarse bin gets whatever the sample says (a bin the quarter
+                                                      // sample missed can hold a handful of keys: 0.44 % of the keys in buckets of four
+                                                      // and more with 1, 0.23 % with 4 — the Poisson figure is 0.22 %)
+    static constexpr int NBE = NBK - WMIN * RK_COARSE; // to distribute by the equalisation
+    // byte offsets inside the workgroup's LDS (dynamic LDS starts at 0: checked once per workgroup).  Everything a DS
+    // instruction addresses with a register + constant lies below 64 KiB + register, so the constant fits the offset field.
+    static constexpr uint32_t MISC_B = 0;             // [32] words
+    static constexpr uint32_t RED_B = 128;            // [64] scan partials (QR x wavefronts)
+    static constexpr uint32_t C1_B = 384;             // [256] coarse histogram
+    static constexpr uint32_t TAB_B = 1408;           // [257] (ww, base + 1/16) per coarse bin
+    static constexpr uint32_t TIE_B = 3472;           // [3][R5_TCAP] key bits, pixel, rank
+    static constexpr uint32_t GS_B = 8192;            // [NWRD] u16 group starts; from here on: the staged source column
+    static constexpr uint32_t CW_B = GS_B + 2u * NWRD;  // [NWRD] counter words -> slots of the keys that share a bucket
+    static constexpr size_t LDS = (size_t)CW_B + 4u * NWRD;
+    static constexpr unsigned SRC_MAX = (6u * NWRD) / 4u;  // staged source values (over the group starts and the counters)
+    static constexpr int SQ = (int)((SRC_MAX / 4u + NT - 1) / NT);  // 16-byte source loads per thread
+    static_assert(NBK <= 65536, "bucket index is 16 bits");
+    static_assert(QR * (NT / 64) <= 64, "one lane per (row, wavefront) partial in the scan");
+    static_assert(TAB_B % 8 == 0 && TIE_B % 16 == 0 && TIE_B + 12u * R5_TCAP <= GS_B && TAB_B + 8u * (RK_COARSE + 1) <= TIE_B, "layout");
+};
+
+enum { R5_M_BAD = 0, R5_M_TN = 2 };
+
+__device__ __forceinline__ unsigned r5_wave_incl_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// phase stamps of thread 0 (probe builds only: -DOPTEX_SORT_PROBE, scripts/sort5_probe.hip)
+#ifdef OPTEX_SORT_PROBE
+#define R5_STAMP(i) do { if (threadIdx.x == 0) a.probe[(size_t)col * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define R5_STAMP(i) do { } while (0)
+#endif
+
+#ifndef R5_G
+#define R5_G 8   // keys whose LDS operations are in flight together in the count / decode steps
+#endif
+
+// NT threads, ITEMS = ceil(n / NT) keys per thread: the first 4 * (ITEMS / 4) registers are 16-byte loads (4 neighbouring
+// pixels), the rest scalar rows; only the last register row (or quad) can be ragged.  FULL: n == ITEMS * NT.
+template <int ITEMS, int NT, bool FULL>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void rank_match5_kernel(SortArgs a) {
+    using K = R5<ITEMS, NT>;
+    constexpr int NW = NT / 64, QR = K::QR, CAP = K::CAP;
+    constexpr uint32_t MISC_B = K::MISC_B, RED_B = K::RED_B, C1_B = K::C1_B, TAB_B = K::TAB_B, TIE_B = K::TIE_B, GS_B = K::GS_B,
+                       CW_B = K::CW_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* misc = reinterpret_cast<uint32_t*>(smem + MISC_B);
+    uint32_t* red = reinterpret_cast<uint32_t*>(smem + RED_B);
+    uint32_t* c1 = reinterpret_cast<uint32_t*>(smem + C1_B);
+    float2* tab = reinterpret_cast<float2*>(smem + TAB_B);
+    uint32_t* tkey = reinterpret_cast<uint32_t*>(smem + TIE_B);
+    uint32_t* tpix = tkey + R5_TCAP;
+    uint32_t* tres = tpix + R5_TCAP;
+
+    const int n = FULL ? CAP : (int)a.n;
+    const unsigned ns = (unsigned)a.ns;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int Q = ITEMS / 4, T = ITEMS - 4 * Q;
+    auto ragged = [](int r) { return !FULL && ((T == 0) ? r >= ITEMS - 4 : r == ITEMS - 1); };
+    auto valid = [&](int r) { return !ragged(r) || ((T == 0) ? tid < (n >> 2) - (r >> 2) * NT : tid < n - r * NT); };
+
+    // a thread index the compiler cannot tie to the other phases' (or the previous column's): otherwise it hoists every
+    // address of every phase out of the column loop and keeps them — 60+ registers — alive (and spilled) for the whole kernel
+    auto otid = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) {  // never on this toolchain
+        for (int cc = blockIdx.x; cc < a.ncols; cc += (int)gridDim.x)
+            if (threadIdx.x == 0) a.flags[cc] = 1;
+        return;
+    }
+
+    // the column's keys (registers past the end hold a copy of a real key: they stay out of every LDS update)
+    auto load_keys = [&](int cc, float (&xx)[ITEMS]) {
+        const int sg = cc / a.C, ch = cc - sg * a.C;
+        const float* src = a.keys + (size_t)((a.x_n_seg == 1) ? 0 : sg) * a.ss + (size_t)ch * a.ld;
+        const int tid = otid();
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int e0 = (q * NT + tid) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(src + (ragged(4 * q) ? (e0 < n ? e0 : 0) : e0));
+            xx[4 * q + 0] = v.x;
+            xx[(4 * q + 1) % ITEMS] = v.y;
+            xx[(4 * q + 2) % ITEMS] = v.z;
+            xx[(4 * q + 3) % ITEMS] = v.w;
+        }
+#pragma unroll
+        for (int r = 4 * Q; r < ITEMS; r++) {
+            const int e = r * NT + tid;
+            xx[r] = src[ragged(r) ? (e < n ? e : n - 1) : e];
+        }
+    };
+
+    float x[ITEMS];
+    int col = blockIdx.x;
+    if (col < a.ncols) load_keys(col, x);
+
+    for (; col < a.ncols; col += (int)gridDim.x) {
+        bool fetched = false;  // the next column's keys are on their way into x
+        const int nxt = col + (int)gridDim.x;
+        do {
+            const int seg = col / a.C, c = col - seg * a.C;
+            const int sseg = (a.src_n_seg == 1) ? 0 : seg;
+            const float* ssrt = a.src_sorted + ((size_t)sseg * a.C + c) * a.ns;
+            float* o = a.out + (size_t)seg * a.oss + (size_t)c * a.ldo;
+            const float lo = a.rng_lo[col], hi = a.rng_hi[col];
+            R5_STAMP(0);
+
+            // ---- 0. clear the counters (the previous column's staged source lies there), the coarse histogram, the flags
+            {
+                const int tz = otid();
+#pragma unroll
+                for (int j = 0; j < QR; j++) R5_LDS(r5_v4u, CW_B + (uint32_t)(j * NT + tz) * 16u) = r5_v4u{0u, 0u, 0u, 0u};
+            }
+            if (tid < RK_COARSE) c1[tid] = 0u;
+            if (tid < 32) misc[tid] = 0u;
+
+            if (!(hi < __uint_as_float(R5_INF)) || !(lo > -__uint_as_float(R5_INF))) {  // non-finite range: radix kernel
+                if (tid == 0) a.flags[col] = 1;
+                break;
+            }
+            if (lo == hi) {
+                if (lo == 0.f) {  // zeros of both signs may be mixed (-0 < +0 in the specification): radix kernel
+                    if (tid == 0) a.flags[col] = 1;
+                    break;
+                }
+                // constant column: already sorted, rank = pixel index
+                for (int e = tid; e < n; e += NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+                break;
+            }
+            const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
+            if (!(s1 > 0.f) || !(s1 < 1.0e37f)) {  // range over / underflow: radix kernel
+                if (tid == 0) a.flags[col] = 1;
+                break;
+            }
+            // non-finite keys inside a finite range cannot happen with an exact range, NaN can (min / max drop it): x * 0
+            float nf = 0.f;
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) nf = __builtin_fmaf(x[r], 0.f, nf);
+            __syncthreads();  // B0: cleared
+            R5_STAMP(1);
+            if (__any(!(nf == 0.f)) && lane == 0) misc[R5_M_BAD] = 1u;
+
+            // ---- 1. coarse histogram of a spatially spread quarter sample
+            constexpr int RS = 4;
+            unsigned nsamp = 0;
+            if (T == 0) {
+                nsamp = (unsigned)(n + 3) / 4u;
+            } else {
+#pragma unroll
+                for (int r = 0; r < ITEMS; r += RS) {
+                    const int left = (r < 4 * Q) ? (n / 4 - (r >> 2) * NT) : (n - r * NT);  // rows: quads, then scalars
+                    nsamp += (unsigned)(left < 0 ? 0 : (left > NT ? NT : left));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ITEMS; r += RS) {
+                if (valid(r)) {
+                    const float t = (x[r] - lo) * s1;
+                    int bin = (int)t;
+                    bin = bin > RK_COARSE - 1 ? RK_COARSE - 1 : bin;
+                    atomicAdd(&c1[bin], 1u);
+                }
+            }
+            __syncthreads();  // B1
+            R5_STAMP(2);
+            // ---- 2. equalisation: coarse bin b gets w_b = WMIN + cnt_b * NBE / nsamp fine buckets from base_b on.  For
+            //         t = (x - lo) * s1 in [b, b + 1):  u = fract(t) * (w_b - 1/8) + (base_b + 1/16)  lies in
+            //         [base + 1/16, base + w - 1/16): both table values are exact in fp32 (17 + 4 bits), the fma rounds once by
+            //         at most 2^-9, so int(u) stays inside the bin's bucket range — monotone over the column, no clamp.
+            if (w == 0) {
+                const uint4 cc = *reinterpret_cast<const uint4*>(c1 + 4 * lane);
+                auto width = [&](unsigned cn) {
+                    const unsigned xx = cn * (unsigned)K::NBE;  // < 2^28: exact quotient via a float estimate + one correction
+                    unsigned q = (unsigned)((float)xx / (float)nsamp);
+                    if (q * nsamp > xx) q--;
+                    else if ((q + 1u) * nsamp <= xx) q++;
+                    return (unsigned)K::WMIN + q;
+                };
+                const unsigned w0 = width(cc.x), w1 = width(cc.y), w2 = width(cc.z), w3 = width(cc.w);
+                const unsigned sum = w0 + w1 + w2 + w3;
+                const unsigned incl = r5_wave_incl_scan(sum);
+                const unsigned b0 = incl - sum, b1 = b0 + w0, b2 = b1 + w1, b3 = b2 + w2;
+                auto entry = [&](unsigned base, unsigned wd) { return make_float2((float)wd - 0.125f, (float)base + 0.0625f); };
+                tab[4 * lane + 0] = entry(b0, w0);
+                tab[4 * lane + 1] = entry(b1, w1);
+                tab[4 * lane + 2] = entry(b2, w2);
+                tab[4 * lane + 3] = entry(b3, w3);
+                // t rounds up to RK_COARSE itself for x = hi: the last bucket of the last bin
+                if (lane == 63) tab[RK_COARSE] = make_float2(0.f, (float)(b3 + w3 - 1u) + 0.0625f);
+            }
+            __syncthreads();  // B2
+            R5_STAMP(3);
+            if (misc[R5_M_BAD] != 0u) {
+                if (tid == 0) a.flags[col] = 1;
+                break;
+            }
+            // ---- 3. fine bucket b of every key; the returning count atomic on the bucket's byte of word b >> 2 gives the
+            //         key's arrival number inside the bucket.  st[r] = b | arrival << 16
+            uint32_t st[ITEMS];
+            constexpr int G = ITEMS < R5_G ? ITEMS : R5_G;
+#pragma unroll
+            for (int g = 0; g < ITEMS; g += G) {
+                float fr[G];
+                r5_v2f e2[G];
+                uint32_t b[G], old[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    if (g + j >= ITEMS) continue;
+                    const float t = (x[g + j] - lo) * s1;
+                    fr[j] = __builtin_amdgcn_fractf(t);
+                    e2[j] = R5_LDS(const r5_v2f, TAB_B + ((uint32_t)t << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    if (g + j >= ITEMS) continue;
+                    b[j] = (uint32_t)__builtin_fmaf(fr[j], e2[j].x, e2[j].y);
+                    // 1 << 8 * (b & 3):  {0x01000000, 0x01000000} >> 8 * (~b & 3)
+                    uint32_t inc = __builtin_amdgcn_alignbyte(0x01000000u, 0x01000000u, ~b[j]);
+                    if (ragged(g + j)) inc = valid(g + j) ? inc : 0u;
+                    old[j] = __hip_atomic_fetch_add(&R5_LDS(uint32_t, CW_B + (b[j] & ~3u)), inc, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    if (g + j >= ITEMS) continue;
+                    const uint32_t arr = __builtin_amdgcn_alignbyte(0u, old[j], b[j]) & 255u;  // byte b & 3 of the old word
+                    st[g + j] = b[j] | (arr << 16);
+                }
+                asm volatile("" ::: "memory");
+            }
+            __syncthreads();  // B3: all counts in
+            R5_STAMP(4);
+            // the sorted source column on its way into registers (staged in step 8)
+            // (rank5_supported: ns % 4 == 0, 16-byte aligned columns, ns <= SRC_MAX — unconditional loads: a conditional one
+            // makes every later use a phi of 4 * SQ registers)
+            // The first SQE 16-byte rows (ns <= 4 * NT * SQE values: every call with ns <= n) now, the rest behind the mate compare,
+            // when the registers are free again (at 16 keys per thread all six rows in flight here spill)
+            constexpr int SQE = K::SQ < QR ? K::SQ : QR;
+            r5_v4f sv[K::SQ];
+            {
+                const int ts = otid();
+#pragma unroll
+                for (int q = 0; q < SQE; q++) {
+                    const unsigned e0 = (unsigned)(q * NT + ts) * 4u;
+                    sv[q] = *reinterpret_cast<const r5_v4f*>(ssrt + (e0 < ns ? e0 : 0u));
+                }
+            }
+            bool ovf = false;
+            // ---- 4. exclusive scan of the counter bytes -> one 16-bit start per word (group of four buckets).  Thread t owns
+            //         the 16-byte rows t, NT + t, ...: conflict-free reads; order = (row, wavefront, lane, word, byte)
+            {
+                r5_v4u cq[QR];
+                unsigned p1[QR], p2[QR], p3[QR], tot[QR], incl[QR];
+                const int tc = otid();
+#pragma unroll
+                for (int j = 0; j < QR; j++) cq[j] = R5_LDS(const r5_v4u, CW_B + (uint32_t)(j * NT + tc) * 16u);
+#pragma unroll
+                for (int j = 0; j < QR; j++) {
+                    p1[j] = __builtin_amdgcn_sad_u8(cq[j].x, 0u, 0u);
+                    p2[j] = __builtin_amdgcn_sad_u8(cq[j].y, 0u, p1[j]);
+                    p3[j] = __builtin_amdgcn_sad_u8(cq[j].z, 0u, p2[j]);
+                    tot[j] = __builtin_amdgcn_sad_u8(cq[j].w, 0u, p3[j]);
+                    incl[j] = r5_wave_incl_scan(tot[j]);
+                    if (lane == 63) red[j * NW + w] = incl[j];
+                }
+                __syncthreads();  // B4a
+                R5_STAMP(5);
+                // every wavefront scans the QR x NW partials itself (one lane each): no second barrier
+                const unsigned pv = lane < QR * NW ? red[lane] : 0u;
+                const unsigned pi = r5_wave_incl_scan(pv);
+                // a bucket of 256 or more keys (massive ties) wraps its 8-bit counter: the carry adds 1 to the next byte (or is
+                // lost) where 256 keys arrived, so the bytes no longer sum to n — the column goes to the radix kernel
+                ovf = (unsigned)__builtin_amdgcn_readlane((int)pi, QR * NW - 1) != (unsigned)n;
+#pragma unroll
+                for (int j = 0; j < QR; j++) {
+                    const int k = j * NW + w;  // wave-uniform
+                    const unsigned base = k == 0 ? 0u : (unsigned)__builtin_amdgcn_readlane((int)pi, k - 1);
+                    const unsigned ex = base + incl[j] - tot[j];
+                    const r5_v2u gs = {ex | ((ex + p1[j]) << 16), (ex + p2[j]) | ((ex + p3[j]) << 16)};
+                    R5_LDS(r5_v2u, GS_B + (uint32_t)(j * NT + tc) * 8u) = gs;
+                }
+            }
+            __syncthreads();  // B4: group starts in place
+            R5_STAMP(6);
+            if (ovf) {  // uniform: every wavefront saw the same total
+                if (tid == 0) a.flags[col] = 1;
+                break;
+            }
+            // ---- 5. every key reads its counter word and its group start:
+            //         start = group start + sum of the bytes below its own, cnt = its own byte.
+            //         st[r] becomes  start | arrival << 16 | cnt << 24  (the bucket index is not needed again)
+#pragma unroll
+            for (int g = 0; g < ITEMS; g += G) {
+                uint32_t cw[G], gs[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    if (g + j >= ITEMS) continue;
+                    cw[j] = R5_LDS(const uint32_t, CW_B + (st[g + j] & 0xfffcu));
+                    gs[j] = R5_LDS(const unsigned short, GS_B + ((st[g + j] >> 1) & 0x7ffeu));
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    if (g + j >= ITEMS) continue;
+                    const uint32_t below = __builtin_amdgcn_alignbyte(cw[j], 0u, st[g + j]);   // bytes 0 .. (b & 3) - 1 of cw, moved up
+                    const uint32_t start = __builtin_amdgcn_sad_u8(below, 0u, gs[j]);
+                    uint32_t cnt = __builtin_amdgcn_alignbyte(0u, cw[j], st[g + j]) << 24;     // byte b & 3 of cw, on top
+                    if (ragged(g + j)) cnt = valid(g + j) ? cnt : (1u << 24);
+                    st[g + j] = ((st[g + j] & 0x00ff0000u) | start) | cnt;
+                }
+                asm volatile("" ::: "memory");
+            }
+            __syncthreads();  // B5: the counters are dead
+            R5_STAMP(7);
+            // ---- 6. keys that share a bucket take slot start + arrival in the counter array
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                if (st[r] >= (2u << 24)) {  // cnt >= 2
+                    const uint32_t pos = (st[r] & 0xffffu) + ((st[r] >> 16) & 255u);
+                    R5_LDS(float, CW_B + (pos << 2)) = x[r];
+                }
+            }
+            __syncthreads();  // B6
+            R5_STAMP(8);
+            // ---- 7. ... and count their smaller bucket mates.  Two mates are read blindly (all keys' reads in flight
+            //         together); buckets of four and more keys loop.  The low half of st[r] becomes the rank (in place: a rank
+            //         stays below 16384), or st[r] = R5_TAG | tie-list entry
+            uint32_t tie = 0u;  // bit r: key r has an equal bucket mate
+            float m1[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                m1[r] = __uint_as_float(R5_INF);
+                if (st[r] >= (2u << 24)) {
+                    const uint32_t j1 = (st[r] & 0x00ff0000u) == 0u ? 1u : 0u;  // first mate: slot 0, or slot 1 for arrival 0
+                    m1[r] = R5_LDS(const float, CW_B + (((st[r] & 0xffffu) + j1) << 2));
+                }
+            }
+            // buckets of four and more keys (0.2 % of the keys, one wavefront row in seven): the whole bucket, four
+            // slots in flight at a time — then out of the way (cnt := 1)
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                if (st[r] >= (4u << 24)) {
+                    const uint32_t start = st[r] & 0xffffu, cnt = st[r] >> 24;
+                    uint32_t lt = 0u, eq = 0u;
+#pragma unroll
+                    for (int j0 = 0; j0 < 8; j0 += 4) {
+                        float mm[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            mm[j] = __uint_as_float(R5_INF);
+                            if ((uint32_t)(j0 + j) < cnt) mm[j] = R5_LDS(const float, CW_B + ((start + (uint32_t)(j0 + j)) << 2));
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            lt += (mm[j] < x[r]) ? 1u : 0u;
+                            eq += (mm[j] == x[r]) ? 1u : 0u;
+                        }
+                        if (j0 == 0 && !__any(cnt > 4u)) break;
+                    }
+                    for (uint32_t j = 8; j < cnt; j++) {  // (only ties fill a bucket like this)
+                        const float m = R5_LDS(const float, CW_B + ((start + j) << 2));
+                        lt += (m < x[r]) ? 1u : 0u;
+                        eq += (m == x[r]) ? 1u : 0u;
+                    }
+                    st[r] = (start + lt) | (1u << 24);
+                    tie |= eq > 1u ? (1u << r) : 0u;
+                    m1[r] = __uint_as_float(R5_INF);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                const uint32_t start = st[r] & 0xffffu;
+                const float mm = m1[r];
+                m1[r] = __uint_as_float(R5_INF);
+                if (st[r] >= (3u << 24)) {  // cnt == 3: the second mate is slot 2, or slot 1 for arrival 2
+                    const uint32_t j2 = (st[r] & 0x00fe0000u) != 0u ? 1u : 2u;
+                    m1[r] = R5_LDS(const float, CW_B + ((start + j2) << 2));
+                }
+                st[r] += (mm < x[r]) ? 1u : 0u;
+                tie |= (mm == x[r]) ? (1u << r) : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                st[r] += (m1[r] < x[r]) ? 1u : 0u;
+                tie |= (m1[r] == x[r]) ? (1u << r) : 0u;
+            }
+            if (tie != 0u) {  // rare: exact ties (and -0 / +0) are ordered by (totalOrder key, pixel) among themselves
+                const int tid = otid();  // (elem(r) below: not sixteen pixel numbers kept alive for the whole kernel)
+                auto elem = [&](int r) { return r < 4 * Q ? ((r >> 2) * NT + tid) * 4 + (r & 3) : r * NT + tid; };
+#pragma unroll
+                for (int r = 0; r < ITEMS; r++) {
+                    if ((tie >> r) & 1u) {
+                        const uint32_t ti = atomicAdd(&misc[R5_M_TN], 1u);
+                        if (ti < (uint32_t)R5_TCAP) {
+                            tkey[ti] = __float_as_uint(x[r]);
+                            tpix[ti] = (uint32_t)elem(r);
+                            tres[ti] = st[r] & 0xffffu;
+                        }
+                        st[r] = R5_TAG | ti;
+                    }
+                }
+            }
+            {
+                const int ts = otid();
+#pragma unroll
+                for (int q = SQE; q < K::SQ; q++) {
+                    const unsigned e0 = (unsigned)(q * NT + ts) * 4u;
+                    sv[q] = *reinterpret_cast<const r5_v4f*>(ssrt + (e0 < ns ? e0 : 0u));
+                }
+            }
+            // the keys are dead: the next column's are requested now and arrive while this one is staged, picked and stored
+            if (nxt < a.ncols) load_keys(nxt, x);
+            fetched = true;
+            __syncthreads();  // B7: every slot has been read, the tie list is complete
+            R5_STAMP(9);
+            const uint32_t tn = misc[R5_M_TN];
+            if (tn > (uint32_t)R5_TCAP) {  // tie-heavy column: radix kernel
+                if (tid == 0) a.flags[col] = 1;
+                break;
+            }
+            for (uint32_t t = tid; t < tn; t += NT) {
+                const uint32_t kb = tkey[t], pix = tpix[t];
+                const float kf = __uint_as_float(kb);
+                const uint32_t kk = f2key(kf);
+                uint32_t before = 0u;
+                for (uint32_t u = 0; u < tn; u++) {
+                    const float jf = __uint_as_float(tkey[u]);
+                    const uint32_t jk = f2key(jf);
+                    // float-equal partners (this includes -0 / +0) ordered by (totalOrder key, pixel); rk counted the
+                    // float-smaller mates only
+                    before += (jf == kf && (jk < kk || (jk == kk && tpix[u] < pix))) ? 1u : 0u;
+                }
+                tres[t] += before;  // only this thread touches tres[t]
+            }
+            // ---- 8. the sorted source column staged over the (dead) group starts and counters
+            {
+                const int tg = otid();
+#pragma unroll
+                for (int q = 0; q < K::SQ; q++) {
+                    const unsigned e0 = (unsigned)(q * NT + tg) * 4u;
+                    if (e0 < ns) R5_LDS(r5_v4f, GS_B + (e0 << 2)) = sv[q];
+                }
+            }
+            __syncthreads();  // B8
+            R5_STAMP(10);
+            if (tn != 0u) {
+#pragma unroll
+                for (int r = 0; r < ITEMS; r++)
+                    if ((st[r] & R5_TAG) != 0u) st[r] = tres[st[r] & ~R5_TAG];
+            }
+            // ---- 9. out[pixel] = sorted_source[q(rank)]
+            float v[ITEMS];
+            auto pick = [&](auto same) {
+#pragma unroll
+                for (int r = 0; r < ITEMS; r++) {
+                    const unsigned rr = ragged(r) ? (valid(r) ? (st[r] & 0xffffu) : 0u) : (st[r] & 0xffffu);
+                    unsigned qi = rr;
+                    if (!decltype(same)::value) {
+                        const double aa = (double)(2u * rr + 1u) * (double)ns;
+                        qi = (unsigned)__builtin_fma(aa, a.inv_2nt, 7.450580596923828e-09);  // quantile_index (sort_common.h)
+                    }
+                    v[r] = R5_LDS(const float, GS_B + (qi << 2));
+                }
+            };
+            if (ns == (unsigned)n) pick(std::true_type{});
+            else pick(std::false_type{});
+            const int to = otid();
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int e0 = (q * NT + to) * 4;
+                if (!ragged(4 * q) || e0 < n)
+                    *reinterpret_cast<float4*>(o + e0) =
+                        make_float4(v[4 * q], v[(4 * q + 1) % ITEMS], v[(4 * q + 2) % ITEMS], v[(4 * q + 3) % ITEMS]);
+            }
+#pragma unroll
+            for (int r = 4 * Q; r < ITEMS; r++)
+                if (valid(r)) o[r * NT + to] = v[r];
+            R5_STAMP(11);
+        } while (0);
+        if (!fetched && nxt < a.ncols) load_keys(nxt, x);
+        __syncthreads();  // B9: the staged source has been read; the next column clears it
+        R5_STAMP(12);
+    }
+}
+
+int device_cu_count();
+
+// Workgroup shape by column length: one 1024-thread workgroup per CU above 8192 keys, two of 512 threads down to 4097, four
+// of 256 below — always 16 wavefronts per CU at a 128-register budget, 9 .. 16 keys per thread (8 .. 16 with 256 threads).
+static int rank5_threads(long n) { return n > 8192 ? 1024 : (n > 4096 ? 512 : 256); }
+
+// Can launch_rank5 take this match?  (everything else stays with rank_match4_kernel)
+bool rank5_supported(const SortArgs& a) {
+    if (!a.rng_lo || !a.rng_hi || !a.src_sorted || !a.out) return false;
+    if (a.n <= 2048 || a.n > SORT_MAX_N) return false;
+    const long nt = rank5_threads(a.n), items = (a.n + nt - 1) / nt;
+    // 16-byte loads and stores: rows on 16-byte boundaries; a keys-per-thread count without scalar rows needs whole quads
+    if (a.ld % 4 != 0 || a.ss % 4 != 0 || (reinterpret_cast<uintptr_t>(a.keys) & 15u) != 0) return false;
+    if (a.ldo % 4 != 0 || a.oss % 4 != 0 || (reinterpret_cast<uintptr_t>(a.out) & 15u) != 0) return false;
+    if (items % 4 == 0 && a.n % 4 != 0) return false;
+    if (items < 4 || items > 16) return false;
+    // the sorted source column is staged with 16-byte loads over the group starts and the counters
+    const long qr = (items + 3) / 4;
+    if (a.ns % 4 != 0 || (reinterpret_cast<uintptr_t>(a.src_sorted) & 15u) != 0 || a.ns > 6 * (4 * nt * qr) / 4) return false;
+    return true;
+}
+
+template <int ITEMS, int NT>
+static int launch_rank5_items(const SortArgs& a, int ncols, hipStream_t st) {
+    const size_t lds = R5<ITEMS, NT>::LDS;
+    const bool full = a.n == (long)ITEMS * NT;
+    int grid = device_cu_count() * (1024 / NT);
+    if (grid > ncols) grid = ncols;
+    auto go = [&](auto kern, DeviceOnce& once) {
+        bool& attr = *once.slot();
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)OPTEX_E_LAUNCH; }
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
+        return (int)OPTEX_OK;
+    };
+    int rc;
+    if (full) {
+        static DeviceOnce once;
+        rc = go(rank_match5_kernel<ITEMS, NT, true>, once);
+    } else {
+        static DeviceOnce once;
+        rc = go(rank_match5_kernel<ITEMS, NT, false>, once);
+    }
+    if (rc) return rc;
+    return check_launch("rank_match5_kernel");
+}
+
+template <int NT>
+static int launch_rank5_nt(const SortArgs& a, int ncols, hipStream_t st) {
+    switch ((int)((a.n + NT - 1) / NT)) {
+        case 8: if (NT == 256) return launch_rank5_items<8, NT>(a, ncols, st);  // (2048 < n: only 256 threads get here)
+        case 9: return launch_rank5_items<9, NT>(a, ncols, st);
+        case 10: return launch_rank5_items<10, NT>(a, ncols, st);
+        case 11: return launch_rank5_items<11, NT>(a, ncols, st);
+        case 12: return launch_rank5_items<12, NT>(a, ncols, st);
+        case 13: return launch_rank5_items<13, NT>(a, ncols, st);
+        case 14: return launch_rank5_items<14, NT>(a, ncols, st);
+        case 15: return launch_rank5_items<15, NT>(a, ncols, st);
+        default: return launch_rank5_items<16, NT>(a, ncols, st);
+    }
+}
+
+int launch_rank5(const SortArgs& a, int ncols, hipStream_t st) {
+    switch (rank5_threads(a.n)) {
+        case 256: return launch_rank5_nt<256>(a, ncols, st);
+        case 512: return launch_rank5_nt<512>(a, ncols, st);
+        default: return launch_rank5_nt<1024>(a, ncols, st);
+    }
+}
+
+}  // namespace optex

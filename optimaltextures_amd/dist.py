@@ -64,13 +64,16 @@ class StyleSync:
 
     STATUS_WORDS = 64  # the mark travels in front of the payload; 64 floats keep every tensor on its 256-byte boundary
 
-    def __init__(self, device, src: int = 0, group=None, always: bool = False, spread: bool = True):
+    def __init__(self, device, src: int = 0, group=None, always: bool = False, spread: bool = False):
         """always=True: issue the broadcasts even in a world of one (tests: the RCCL call sequence on one GPU).
-        spread=True (default): when every shape is known in advance (no PCA) the driver lets rank (src + p) mod world encode
-        and send the style side of pass p — EVERY rank must then hold the real style images (bench.py and the CLI load them
-        on every rank); spread=False: everything comes from `src`, the other ranks' style images are never looked at."""
+        spread=False (default): everything comes from `src` (a rank of `group`), the other ranks' style images are never
+        looked at — placeholders of the right shape are enough there.  spread=True (bench.py and the CLI opt in: they load
+        the real style images on every rank): when every shape is known in advance (no PCA) the driver lets group rank
+        (src + p) mod world encode and send the style side of pass p — EVERY rank must then hold the real style images;
+        a rank that holds placeholders would send garbage for its passes, and nothing can tell."""
         self.device, self.src, self.group, self.always = torch.device(device), src, group, always
         self.spread = bool(spread)
+        self._deferred = None   # a bad-source error of a spread exchange, raised once the call's exchanges are all issued
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_moved = 0    # payload + header bytes this rank sent or received
@@ -101,17 +104,30 @@ class StyleSync:
     def header_len(n_tensors: int, n_ints: int) -> int:
         return 3 + n_tensors * (1 + MAX_DIMS) + n_ints
 
-    def broadcast_known(self, tensors: Optional[List[torch.Tensor]], shapes: List[Tuple[int, ...]], src: Optional[int] = None):
+    def raise_deferred(self):
+        """Behind the last `defer=True` exchange of a call: raise the bad-source error kept back on the source, and look at the
+        marks received so far (all of them on a host backend; on a GPU those whose copy has completed — never blocking)."""
+        err, self._deferred = self._deferred, None
+        if err is not None:
+            raise err
+        self.verify()
+
+    def broadcast_known(self, tensors: Optional[List[torch.Tensor]], shapes: List[Tuple[int, ...]], src: Optional[int] = None,
+                        defer: bool = False):
         """The exchange when every rank can compute every SHAPE in advance (no PCA: the rank k is the only data-dependent
         size): no header, no host synchronisation at all — ONE asynchronous payload broadcast; the receiving ranks keep
         enqueueing kernels behind it.  source: list of fp32 tensors of exactly these shapes -> everyone: the tensors.
         src: the rank that holds the tensors of THIS exchange (default: the hook's source rank) — the driver spreads the style
-        sides of a call's passes over the ranks, one source each (OptimalTexture.prefetch_style_sides)."""
+        sides of a call's passes over the ranks, one source each (OptimalTexture.prefetch_style_sides).
+        defer=True: nothing raises here — neither a source whose tensors are bad nor a receiver that has seen a mark — but in
+        raise_deferred(): for a sequence of exchanges with different sources every rank has to issue ALL of them, or the
+        ranks that go on hang in the next collective."""
         if self.world == 1 and not self.always:
             return list(tensors)
-        src = self.src if src is None else int(src)
+        src = self.src if src is None else int(src)  # a rank of `group` (like self.rank), mapped to the global rank below
         is_source = self.rank == src
-        self.verify()
+        if not defer:
+            self.verify()
         numels = [int(torch.Size(sh).numel()) for sh in shapes]
         head = self.STATUS_WORDS
         total = head + sum(_padded(k) for k in numels)
@@ -130,7 +146,8 @@ class StyleSync:
                 for t, k in zip(tensors, numels):
                     flat[off:off + k].copy_(t.reshape(-1))
                     off += _padded(k)
-        work = dist.broadcast(flat, src, group=self.group, async_op=True)
+        gsrc = src if self.group is None else dist.get_global_rank(self.group, src)
+        work = dist.broadcast(flat, gsrc, group=self.group, async_op=True)
         self.messages += 1
         self.bytes_moved += total * 4
         out, off = [], head
@@ -139,17 +156,26 @@ class StyleSync:
             off += _padded(k)
         work.wait()  # RCCL: the current stream waits for the communicator's stream, the host does not block
         if is_source and bad:
-            raise ValueError("StyleSync.broadcast_known: the source rank's tensors do not have the announced shapes")
+            err = ValueError("StyleSync.broadcast_known: the source rank's tensors do not have the announced shapes")
+            if defer:
+                # a call with several exchanges from rotating sources (spread mode): this rank must still JOIN the later ones —
+                # the receivers only poll the mark and go on to the next broadcast — so the error is kept until
+                # raise_deferred(), which the driver calls behind the last exchange of the call
+                self._deferred = self._deferred or err
+                return out
+            raise err
         if flat.is_cuda:
             host = torch.empty(1, dtype=torch.float32, pin_memory=True)
             host.copy_(flat[:1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self._pending.append((host, ev))
-            self.verify()
+            if not defer:
+                self.verify()
         else:
             self._pending.append((flat[:1], None))
-            self.verify(block=True)
+            if not defer:
+                self.verify(block=True)
         return out
 
     def broadcast_packed(self, tensors: Optional[List[torch.Tensor]], ints: Optional[List[int]] = None,

@@ -409,9 +409,11 @@ class OptimalTexture(torch.nn.Module):
         size, which is known in advance (each pass leaves the pastiche at its content size).  With a style_sync hook the
         source rank encodes them all and ONE exchange carries them.
         Without PCA every shape is computable on every rank (Encoder.out_shape of the — globally known — style image size):
-        the exchange is a single asynchronous payload broadcast with NO host synchronisation on any rank
-        (StyleSync.broadcast_known); `styles` must then have the true shapes on every rank, their content matters on the
-        source rank only.  With PCA the rank k is data dependent: one int64 header (the one host synchronisation of a
+        the exchange is one asynchronous payload broadcast per pass with NO host synchronisation on any rank
+        (StyleSync.broadcast_known); `styles` must then have the true shapes on every rank.  Their CONTENT matters on the
+        source rank only with the hook's default (StyleSync(spread=False)); a hook built with spread=True lets group rank
+        (src + p) mod world encode pass p from ITS `styles`, so every rank must hold the real images (bench.py and the CLI
+        do).  With PCA the rank k is data dependent: one int64 header (the one host synchronisation of a
         forward call on the receiving ranks) precedes the payload (StyleSync.broadcast_packed)."""
         hw, plan = (int(pastiche_hw[0]), int(pastiche_hw[1])), []
         need = self.style_sync is None or self.style_sync.is_source
@@ -448,8 +450,9 @@ class OptimalTexture(torch.nn.Module):
             flat = None
             if sync.rank == src:
                 flat = self._compute_style_sides([self._style_tensors(styles, size, resized)])[0][0]
-            feats = sync.broadcast_known(flat, shapes, src=src)
+            feats = sync.broadcast_known(flat, shapes, src=src, defer=True)
             out.append((resized, feats, [torch.empty((0, 0), device=f.device) for f in feats], hws))
+        sync.raise_deferred()  # a source with bad tensors has joined every exchange of the call before it raises
         return out
 
     def rotation_schedule(self, sides=None):

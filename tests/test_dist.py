@@ -370,6 +370,38 @@ def _known_shapes_round_robin_job(rank, world, device):
     return got, sync.messages
 
 
+def _known_shapes_deferred_error_job(rank, world, device):
+    """in spread mode a source whose tensors are bad must still JOIN the call's later exchanges (their sources are
+    other ranks, and the receivers only poll the mark): with defer=True it completes all five and raises in raise_deferred();
+    the other rank raises from the mark.  Nobody hangs."""
+    sync = otdist.StyleSync(device, spread=True)
+    issued, raised = 0, False
+    try:
+        for p in range(5):
+            src = p % world
+            payload = None
+            if rank == src:
+                payload = [torch.zeros(3)] if (p == 1) else [torch.full((1, 4, 6), float(p))]   # pass 1's source (rank 1) is bad
+            sync.broadcast_known(payload, [(1, 4, 6)], src=src, defer=True)
+            issued += 1
+        sync.raise_deferred()
+        sync.verify(block=True)
+    except ValueError:
+        raised = True
+    return issued, raised
+
+
+def test_style_sync_spread_bad_source_joins_every_exchange_before_raising_gloo_world2():
+    res = run_world(_known_shapes_deferred_error_job, 2)
+    assert res[1] == (5, True)            # the bad source issued all five exchanges, then raised
+    assert res[0][1] is True              # the receiver raised from the mark (gloo: at the exchange it arrived with)
+
+
+def test_style_sync_defaults_to_one_source():
+    """the hook's default is spread=False — placeholders on ranks != src are a supported contract"""
+    assert otdist.StyleSync(torch.device("cpu")).spread is False
+
+
 def test_style_sync_known_shapes_one_source_per_pass_gloo_world2():
     res = run_world(_known_shapes_round_robin_job, 2)
     (a, ma), (b, mb) = res[0], res[1]
