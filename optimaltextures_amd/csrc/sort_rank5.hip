@@ -537,6 +537,495 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 int device_cu_count();
 
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifndef R5W_H16
+#define R5W_H16 4
+#endif
+// rank_match5w_kernel: the same ranking step at a 64-register budget, ONE column per workgroup, TWO (or more) workgroups per CU
+// like rank_match4_kernel — the counters shrink to three buckets per key (NWRD = 12 * NT words at 13 .. 16 keys per thread:
+// 8 KiB + 72 KiB = exactly half the LDS), so that while one workgroup waits at a barrier or for its column the other one issues.
+// (profiles/r06_sort_experiments.md: the one-workgroup-per-CU kernel above has 30 % fewer LDS cycles and 15 % fewer VALU
+// instructions than rank_match4_kernel and is still slower — 16 wavefronts per CU leave the VALU idle 40 % of the time.)
+template <int ITEMS, int NT>
+struct R5W {
+    static constexpr int CAP = ITEMS * NT;
+    static constexpr int QR = (ITEMS * 3 + 15) / 16;  // 16-byte rows of counter words per thread: ~3 words = 12 buckets per 4 keys
+    static constexpr int NWRD = 4 * NT * QR;
+    static constexpr int NBK = 4 * NWRD;
+    static constexpr int WMIN = 4;
+    static constexpr int NBE = NBK - WMIN * RK_COARSE;
+    static constexpr uint32_t MISC_B = 0, RED_B = 128, C1_B = 384, TAB_B = 1408, TIE_B = 3472, GS_B = 8192;
+    static constexpr uint32_t CW_B = GS_B + 2u * NWRD;
+    static constexpr size_t LDS = (size_t)CW_B + 4u * NWRD;
+    static constexpr int SQ = (6 * NWRD / 16 + NT - 1) / NT < 4 ? (6 * NWRD / 16 + NT - 1) / NT : 4;  // 16-byte source loads per thread
+    static constexpr unsigned SRC_MAX = (unsigned)(6 * NWRD / 4) < (unsigned)(16 * NT * SQ / 4) ? (unsigned)(6 * NWRD / 4) : (unsigned)(4 * NT * SQ);
+    static_assert(NBK <= 65536 && QR * (NT / 64) <= 64 && 6 * QR >= ITEMS, "layout: 6 * NWRD bytes hold one 4-byte slot per key");
+};
+
+template <int ITEMS, int NT, bool FULL>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match5w_kernel(SortArgs a) {
+    using K = R5W<ITEMS, NT>;
+    constexpr int NW = NT / 64, QR = K::QR, CAP = K::CAP;
+    constexpr uint32_t MISC_B = K::MISC_B, RED_B = K::RED_B, C1_B = K::C1_B, TAB_B = K::TAB_B, TIE_B = K::TIE_B, GS_B = K::GS_B,
+                       CW_B = K::CW_B;
+    // a key that shares its bucket sits in slot start + arrival < n: the slots need n words, the counters have only NWRD >= 2 n / 3 —
+    // they lie over the group starts AND the counters (6 * NWRD bytes, both dead behind the decode step's barrier)
+    constexpr uint32_t SLOT_B = GS_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* misc = reinterpret_cast<uint32_t*>(smem + MISC_B);
+    uint32_t* red = reinterpret_cast<uint32_t*>(smem + RED_B);
+    uint32_t* c1 = reinterpret_cast<uint32_t*>(smem + C1_B);
+    float2* tab = reinterpret_cast<float2*>(smem + TAB_B);
+    uint32_t* tkey = reinterpret_cast<uint32_t*>(smem + TIE_B);
+    uint32_t* tpix = tkey + R5_TCAP;
+    uint32_t* tres = tpix + R5_TCAP;
+
+    const int n = FULL ? CAP : (int)a.n;
+    const unsigned ns = (unsigned)a.ns;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int Q = ITEMS / 4, T = ITEMS - 4 * Q;
+    auto ragged = [](int r) { return !FULL && ((T == 0) ? r >= ITEMS - 4 : r == ITEMS - 1); };
+    auto valid = [&](int r) { return !ragged(r) || ((T == 0) ? tid < (n >> 2) - (r >> 2) * NT : tid < n - r * NT); };
+    auto otid = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    const int col = blockIdx.x;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) {  // never on this toolchain
+        if (threadIdx.x == 0) a.flags[col] = 1;
+        return;
+    }
+    const int seg = col / a.C, c = col - seg * a.C;
+    const float* src = a.keys + (size_t)((a.x_n_seg == 1) ? 0 : seg) * a.ss + (size_t)c * a.ld;
+    const float* ssrt = a.src_sorted + ((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * a.ns;
+    float* o = a.out + (size_t)seg * a.oss + (size_t)c * a.ldo;
+
+    float x[ITEMS];
+    {
+        const int tl = otid();
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int e0 = (q * NT + tl) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(src + (ragged(4 * q) ? (e0 < n ? e0 : 0) : e0));
+            x[4 * q + 0] = v.x;
+            x[(4 * q + 1) % ITEMS] = v.y;
+            x[(4 * q + 2) % ITEMS] = v.z;
+            x[(4 * q + 3) % ITEMS] = v.w;
+        }
+#pragma unroll
+        for (int r = 4 * Q; r < ITEMS; r++) {
+            const int e = r * NT + tl;
+            x[r] = src[ragged(r) ? (e < n ? e : n - 1) : e];
+        }
+    }
+    const float lo = a.rng_lo[col], hi = a.rng_hi[col];
+    // ---- 0. clear the counters, the coarse histogram, the flags
+    {
+        const int tz = otid();
+#pragma unroll
+        for (int j = 0; j < QR; j++) R5_LDS(r5_v4u, CW_B + (uint32_t)(j * NT + tz) * 16u) = r5_v4u{0u, 0u, 0u, 0u};
+    }
+    if (tid < RK_COARSE) c1[tid] = 0u;
+    if (tid < 32) misc[tid] = 0u;
+    if (!(hi < __uint_as_float(R5_INF)) || !(lo > -__uint_as_float(R5_INF))) {  // non-finite range: radix kernel
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    if (lo == hi) {
+        if (lo == 0.f) {  // zeros of both signs may be mixed (-0 < +0 in the specification): radix kernel
+            if (tid == 0) a.flags[col] = 1;
+            return;
+        }
+        for (int e = tid; e < n; e += NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+        return;
+    }
+    const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
+    if (!(s1 > 0.f) || !(s1 < 1.0e37f)) {  // range over / underflow: radix kernel
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    __syncthreads();  // B0: cleared (passed while the column is still on its way)
+    {
+        float nf = 0.f;
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) nf = __builtin_fmaf(x[r], 0.f, nf);
+        if (__any(!(nf == 0.f)) && lane == 0) misc[R5_M_BAD] = 1u;
+    }
+    // ---- 1. coarse histogram of a spatially spread quarter sample
+    constexpr int RS = 4;
+    unsigned nsamp = 0;
+    if (T == 0) {
+        nsamp = (unsigned)(n + 3) / 4u;
+    } else {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r += RS) {
+            const int left = (r < 4 * Q) ? (n / 4 - (r >> 2) * NT) : (n - r * NT);
+            nsamp += (unsigned)(left < 0 ? 0 : (left > NT ? NT : left));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; r += RS) {
+        if (valid(r)) {
+            const float t = (x[r] - lo) * s1;
+            int bin = (int)t;
+            bin = bin > RK_COARSE - 1 ? RK_COARSE - 1 : bin;
+            atomicAdd(&c1[bin], 1u);
+        }
+    }
+    __syncthreads();  // B1
+    // ---- 2. equalisation (see rank_match5_kernel)
+    if (w == 0) {
+        const uint4 cc = *reinterpret_cast<const uint4*>(c1 + 4 * lane);
+        auto width = [&](unsigned cn) {
+            const unsigned xx = cn * (unsigned)K::NBE;
+            unsigned q = (unsigned)((float)xx / (float)nsamp);
+            if (q * nsamp > xx) q--;
+            else if ((q + 1u) * nsamp <= xx) q++;
+            return (unsigned)K::WMIN + q;
+        };
+        const unsigned w0 = width(cc.x), w1 = width(cc.y), w2 = width(cc.z), w3 = width(cc.w);
+        const unsigned sum = w0 + w1 + w2 + w3;
+        const unsigned incl = r5_wave_incl_scan(sum);
+        const unsigned b0 = incl - sum, b1 = b0 + w0, b2 = b1 + w1, b3 = b2 + w2;
+        auto entry = [&](unsigned base, unsigned wd) { return make_float2((float)wd - 0.125f, (float)base + 0.0625f); };
+        tab[4 * lane + 0] = entry(b0, w0);
+        tab[4 * lane + 1] = entry(b1, w1);
+        tab[4 * lane + 2] = entry(b2, w2);
+        tab[4 * lane + 3] = entry(b3, w3);
+        if (lane == 63) tab[RK_COARSE] = make_float2(0.f, (float)(b3 + w3 - 1u) + 0.0625f);
+    }
+    __syncthreads();  // B2
+    if (misc[R5_M_BAD] != 0u) {
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    // ---- 3. fine bucket + returning count atomic.  st[r] = b | arrival << 16
+    uint32_t st[ITEMS];
+    constexpr int G = ITEMS < 4 ? ITEMS : 4;
+#pragma unroll
+    for (int g = 0; g < ITEMS; g += G) {
+        float fr[G];
+        r5_v2f e2[G];
+        uint32_t b[G], old[G];
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            if (g + j >= ITEMS) continue;
+            asm volatile("" : "+v"(x[g + j]));  // (keeps the differences x - lo from being formed ahead, next to the sample's)
+            const float t = (x[g + j] - lo) * s1;
+            fr[j] = __builtin_amdgcn_fractf(t);
+            e2[j] = R5_LDS(const r5_v2f, TAB_B + ((uint32_t)t << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            if (g + j >= ITEMS) continue;
+            b[j] = (uint32_t)__builtin_fmaf(fr[j], e2[j].x, e2[j].y);
+            uint32_t inc = __builtin_amdgcn_alignbyte(0x01000000u, 0x01000000u, ~b[j]);
+            if (ragged(g + j)) inc = valid(g + j) ? inc : 0u;
+            old[j] = __hip_atomic_fetch_add(&R5_LDS(uint32_t, CW_B + (b[j] & ~3u)), inc, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            if (g + j >= ITEMS) continue;
+            const uint32_t arr = __builtin_amdgcn_alignbyte(0u, old[j], b[j]) & 255u;
+            st[g + j] = b[j] | (arr << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < G; j++)
+            if (g + j < ITEMS) asm volatile("" : "+v"(st[g + j]));
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();  // B3
+    // ---- 4. scan of the counter bytes -> 16-bit group starts
+    bool ovf = false;
+    {
+        r5_v4u cq[QR];
+        unsigned p1[QR], p2[QR], p3[QR], tot[QR], incl[QR];
+        const int tc = otid();
+#pragma unroll
+        for (int j = 0; j < QR; j++) cq[j] = R5_LDS(const r5_v4u, CW_B + (uint32_t)(j * NT + tc) * 16u);
+#pragma unroll
+        for (int j = 0; j < QR; j++) {
+            p1[j] = __builtin_amdgcn_sad_u8(cq[j].x, 0u, 0u);
+            p2[j] = __builtin_amdgcn_sad_u8(cq[j].y, 0u, p1[j]);
+            p3[j] = __builtin_amdgcn_sad_u8(cq[j].z, 0u, p2[j]);
+            tot[j] = __builtin_amdgcn_sad_u8(cq[j].w, 0u, p3[j]);
+            incl[j] = r5_wave_incl_scan(tot[j]);
+            if (lane == 63) red[j * NW + w] = incl[j];
+        }
+        __syncthreads();  // B4a
+        const unsigned pv = lane < QR * NW ? red[lane] : 0u;
+        const unsigned pi = r5_wave_incl_scan(pv);
+        ovf = (unsigned)__builtin_amdgcn_readlane((int)pi, QR * NW - 1) != (unsigned)n;
+#pragma unroll
+        for (int j = 0; j < QR; j++) {
+            const int k = j * NW + w;
+            const unsigned base = k == 0 ? 0u : (unsigned)__builtin_amdgcn_readlane((int)pi, k - 1);
+            const unsigned ex = base + incl[j] - tot[j];
+            const r5_v2u gs = {ex | ((ex + p1[j]) << 16), (ex + p2[j]) | ((ex + p3[j]) << 16)};
+            R5_LDS(r5_v2u, GS_B + (uint32_t)(j * NT + tc) * 8u) = gs;
+        }
+    }
+    __syncthreads();  // B4
+    if (ovf) {
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    // ---- 5. decode: st[r] = start | arrival << 16 | cnt << 24
+#pragma unroll
+    for (int g = 0; g < ITEMS; g += G) {
+        uint32_t cw[G], gs[G];
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            if (g + j >= ITEMS) continue;
+            cw[j] = R5_LDS(const uint32_t, CW_B + (st[g + j] & 0xfffcu));
+            gs[j] = R5_LDS(const unsigned short, GS_B + ((st[g + j] >> 1) & 0x7ffeu));
+        }
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            if (g + j >= ITEMS) continue;
+            const uint32_t below = __builtin_amdgcn_alignbyte(cw[j], 0u, st[g + j]);
+            const uint32_t start = __builtin_amdgcn_sad_u8(below, 0u, gs[j]);
+            uint32_t cnt = __builtin_amdgcn_alignbyte(0u, cw[j], st[g + j]) << 24;
+            if (ragged(g + j)) cnt = valid(g + j) ? cnt : (1u << 24);
+            st[g + j] = ((st[g + j] & 0x00ff0000u) | start) | cnt;
+        }
+#pragma unroll
+        for (int j = 0; j < G; j++)
+            if (g + j < ITEMS) asm volatile("" : "+v"(st[g + j]));
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();  // B5
+    // ---- 6. place the keys that share a bucket
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        if (st[r] >= (2u << 24)) {
+            const uint32_t pos = (st[r] & 0xffffu) + ((st[r] >> 16) & 255u);
+            R5_LDS(float, SLOT_B + (pos << 2)) = x[r];
+        }
+    }
+    __syncthreads();  // B6
+    // ---- 7. mates, eight keys at a time (register budget)
+    uint32_t tie = 0u;
+    constexpr int H = ITEMS < 8 ? ITEMS : (ITEMS > 13 ? R5W_H16 : 8);
+#pragma unroll
+    for (int h = 0; h < ITEMS; h += H) {
+        float m1[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const int r = h + k;
+            if (r >= ITEMS) continue;
+            m1[k] = __uint_as_float(R5_INF);
+            if (st[r] >= (2u << 24)) {
+                const uint32_t j1 = (st[r] & 0x00ff0000u) == 0u ? 1u : 0u;
+                m1[k] = R5_LDS(const float, SLOT_B + (((st[r] & 0xffffu) + j1) << 2));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const int r = h + k;
+            if (r >= ITEMS) continue;
+            if (st[r] >= (4u << 24)) {  // rare: the whole bucket
+                const uint32_t start = st[r] & 0xffffu, cnt = st[r] >> 24;
+                uint32_t lt = 0u, eq = 0u;
+                for (uint32_t j = 0; j < cnt; j += 4u) {
+                    float mm[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        mm[i] = __uint_as_float(R5_INF);
+                        if (j + (uint32_t)i < cnt) mm[i] = R5_LDS(const float, SLOT_B + ((start + j + (uint32_t)i) << 2));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        lt += (mm[i] < x[r]) ? 1u : 0u;
+                        eq += (mm[i] == x[r]) ? 1u : 0u;
+                    }
+                }
+                st[r] = (start + lt) | (1u << 24);
+                tie |= eq > 1u ? (1u << r) : 0u;
+                m1[k] = __uint_as_float(R5_INF);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const int r = h + k;
+            if (r >= ITEMS) continue;
+            const uint32_t start = st[r] & 0xffffu;
+            const float mm = m1[k];
+            m1[k] = __uint_as_float(R5_INF);
+            if (st[r] >= (3u << 24)) {
+                const uint32_t j2 = (st[r] & 0x00fe0000u) != 0u ? 1u : 2u;
+                m1[k] = R5_LDS(const float, SLOT_B + ((start + j2) << 2));
+            }
+            st[r] += (mm < x[r]) ? 1u : 0u;
+            tie |= (mm == x[r]) ? (1u << r) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const int r = h + k;
+            if (r >= ITEMS) continue;
+            st[r] += (m1[k] < x[r]) ? 1u : 0u;
+            tie |= (m1[k] == x[r]) ? (1u << r) : 0u;
+        }
+        asm volatile("" ::: "memory");
+    }
+    if (tie != 0u) {
+        const int tt = otid();
+        auto elem = [&](int r) { return r < 4 * Q ? ((r >> 2) * NT + tt) * 4 + (r & 3) : r * NT + tt; };
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            if ((tie >> r) & 1u) {
+                const uint32_t ti = atomicAdd(&misc[R5_M_TN], 1u);
+                if (ti < (uint32_t)R5_TCAP) {
+                    tkey[ti] = __float_as_uint(x[r]);
+                    tpix[ti] = (uint32_t)elem(r);
+                    tres[ti] = st[r] & 0xffffu;
+                }
+                st[r] = R5_TAG | ti;
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+    // the keys are dead: the sorted source column on its way into their registers
+    r5_v4f sv[K::SQ];
+    {
+        const int ts = otid();
+#pragma unroll
+        for (int q = 0; q < K::SQ; q++) {
+            const unsigned e0 = (unsigned)(q * NT + ts) * 4u;
+            sv[q] = *reinterpret_cast<const r5_v4f*>(ssrt + (e0 < ns ? e0 : 0u));
+        }
+    }
+    __syncthreads();  // B7
+    const uint32_t tn = misc[R5_M_TN];
+    if (tn > (uint32_t)R5_TCAP) {
+        if (tid == 0) a.flags[col] = 1;
+        return;
+    }
+    for (uint32_t t = tid; t < tn; t += NT) {
+        const uint32_t kb = tkey[t], pix = tpix[t];
+        const float kf = __uint_as_float(kb);
+        const uint32_t kk = f2key(kf);
+        uint32_t before = 0u;
+        for (uint32_t u = 0; u < tn; u++) {
+            const float jf = __uint_as_float(tkey[u]);
+            const uint32_t jk = f2key(jf);
+            before += (jf == kf && (jk < kk || (jk == kk && tpix[u] < pix))) ? 1u : 0u;
+        }
+        tres[t] += before;
+    }
+    // ---- 8. stage the source
+    {
+        const int tg = otid();
+#pragma unroll
+        for (int q = 0; q < K::SQ; q++) {
+            const unsigned e0 = (unsigned)(q * NT + tg) * 4u;
+            if (e0 < ns) R5_LDS(r5_v4f, GS_B + (e0 << 2)) = sv[q];
+        }
+    }
+    __syncthreads();  // B8
+    if (tn != 0u) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++)
+            if ((st[r] & R5_TAG) != 0u) st[r] = tres[st[r] & ~R5_TAG];
+    }
+    // ---- 9. pick and store
+    float v[ITEMS];
+    auto pick = [&](auto same) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const unsigned rr = ragged(r) ? (valid(r) ? (st[r] & 0xffffu) : 0u) : (st[r] & 0xffffu);
+            unsigned qi = rr;
+            if (!decltype(same)::value) {
+                const double aa = (double)(2u * rr + 1u) * (double)ns;
+                qi = (unsigned)__builtin_fma(aa, a.inv_2nt, 7.450580596923828e-09);
+            }
+            v[r] = R5_LDS(const float, GS_B + (qi << 2));
+            if ((r & 3) == 3) asm volatile("" ::: "memory");
+        }
+    };
+    if (ns == (unsigned)n) pick(std::true_type{});
+    else pick(std::false_type{});
+    const int to = otid();
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int e0 = (q * NT + to) * 4;
+        if (!ragged(4 * q) || e0 < n)
+            *reinterpret_cast<float4*>(o + e0) = make_float4(v[4 * q], v[(4 * q + 1) % ITEMS], v[(4 * q + 2) % ITEMS], v[(4 * q + 3) % ITEMS]);
+    }
+#pragma unroll
+    for (int r = 4 * Q; r < ITEMS; r++)
+        if (valid(r)) o[r * NT + to] = v[r];
+}
+
+static int rank5w_threads(long n) { return n > 5120 ? 1024 : 512; }
+
+bool rank5w_supported(const SortArgs& a) {
+    if (!a.rng_lo || !a.rng_hi || !a.src_sorted || !a.out) return false;
+    if (a.n <= 2048 || a.n > SORT_MAX_N) return false;
+    const long nt = rank5w_threads(a.n), items = (a.n + nt - 1) / nt;
+    if (a.ld % 4 != 0 || a.ss % 4 != 0 || (reinterpret_cast<uintptr_t>(a.keys) & 15u) != 0) return false;
+    if (a.ldo % 4 != 0 || a.oss % 4 != 0 || (reinterpret_cast<uintptr_t>(a.out) & 15u) != 0) return false;
+    if (items % 4 == 0 && a.n % 4 != 0) return false;
+    if (items < 4 || items > 16) return false;
+    const long qr = (items * 3 + 15) / 16, nwrd = 4 * nt * qr;
+    long sq = (6 * nwrd / 16 + nt - 1) / nt;
+    if (sq > 4) sq = 4;
+    const long src_max = 6 * nwrd / 4 < 4 * nt * sq ? 6 * nwrd / 4 : 4 * nt * sq;
+    if (a.ns % 4 != 0 || (reinterpret_cast<uintptr_t>(a.src_sorted) & 15u) != 0 || a.ns > src_max) return false;
+    return true;
+}
+
+template <int ITEMS, int NT>
+static int launch_rank5w_items(const SortArgs& a, int ncols, hipStream_t st) {
+    const size_t lds = R5W<ITEMS, NT>::LDS;
+    const bool full = a.n == (long)ITEMS * NT;
+    auto go = [&](auto kern, DeviceOnce& once) {
+        bool& attr = *once.slot();
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error("sort: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)OPTEX_E_LAUNCH; }
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(ncols), dim3(NT), lds, st, a);
+        return (int)OPTEX_OK;
+    };
+    int rc;
+    if (full) {
+        static DeviceOnce once;
+        rc = go(rank_match5w_kernel<ITEMS, NT, true>, once);
+    } else {
+        static DeviceOnce once;
+        rc = go(rank_match5w_kernel<ITEMS, NT, false>, once);
+    }
+    if (rc) return rc;
+    return check_launch("rank_match5w_kernel");
+}
+
+template <int NT>
+static int launch_rank5w_nt(const SortArgs& a, int ncols, hipStream_t st) {
+    switch ((int)((a.n + NT - 1) / NT)) {
+        case 4: return launch_rank5w_items<4, NT>(a, ncols, st);
+        case 5: return launch_rank5w_items<5, NT>(a, ncols, st);
+        case 6: return launch_rank5w_items<6, NT>(a, ncols, st);
+        case 7: return launch_rank5w_items<7, NT>(a, ncols, st);
+        case 8: return launch_rank5w_items<8, NT>(a, ncols, st);
+        case 9: return launch_rank5w_items<9, NT>(a, ncols, st);
+        case 10: return launch_rank5w_items<10, NT>(a, ncols, st);
+        case 11: return launch_rank5w_items<11, NT>(a, ncols, st);
+        case 12: return launch_rank5w_items<12, NT>(a, ncols, st);
+        case 13: return launch_rank5w_items<13, NT>(a, ncols, st);
+        case 14: return launch_rank5w_items<14, NT>(a, ncols, st);
+        case 15: return launch_rank5w_items<15, NT>(a, ncols, st);
+        default: return launch_rank5w_items<16, NT>(a, ncols, st);
+    }
+}
+
+int launch_rank5w(const SortArgs& a, int ncols, hipStream_t st) {
+    return rank5w_threads(a.n) == 512 ? launch_rank5w_nt<512>(a, ncols, st) : launch_rank5w_nt<1024>(a, ncols, st);
+}
+
 // Workgroup shape by column length: one 1024-thread workgroup per CU above 8192 keys, two of 512 threads down to 4097, four
 // of 256 below — always 16 wavefronts per CU at a 128-register budget, 9 .. 16 keys per thread (8 .. 16 with 256 threads).
 static int rank5_threads(long n) { return n > 8192 ? 1024 : (n > 4096 ? 512 : 256); }

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     const long sizes[5] = {16384, 12544, 9216, 6400, 4096};
     const double weight[5] = {8, 9, 10, 12, 13};  // iterations per pass size (relu3_1, 512^2)
     for (int ratio = 0; ratio < (only_n ? 1 : 2); ratio++) {
-        double tot_us[2] = {0, 0}, tot_bytes = 0;
+        double tot_us[3] = {0, 0, 0}, tot_bytes = 0;
         for (int si = 0; si < 5; si++) {
             const long n = sizes[si], ns = ratio == 0 ? n * 3 / 4 : n * 23 / 16;
             if (only_n && n != only_n) continue;
@@ -75,7 +75,8 @@ int main(int argc, char** argv) {
             a.rng_lo = dlo; a.rng_hi = dhi;
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int kern = 0; kern < 2; kern++) {
+            for (int kern = 0; kern < 3; kern++) {
+                if (kern == 2 && !optex::rank5w_supported(a)) { printf("n = %5ld ns = %5ld rank5w: not supported\n", n, ns); continue; }
                 if (kern == 1 && !optex::rank5_supported(a)) { printf("n = %5ld ns = %5ld rank5: not supported\n", n, ns); continue; }
                 float best = 1e30f, ms = 0.f;
                 for (int it = 0; it < reps + 1; it++) {
@@ -83,7 +84,8 @@ int main(int argc, char** argv) {
                     hipMemset(out, 0xff, h.size() * 4);
                     hipEventRecord(e0, 0);
                     if (kern == 0) optex::launch_rank4(optex::SORT_MATCH, a, ncols, 0);
-                    else optex::launch_rank5(a, ncols, 0);
+                    else if (kern == 1) optex::launch_rank5(a, ncols, 0);
+                    else optex::launch_rank5w(a, ncols, 0);
                     hipEventRecord(e1, 0);
                     hipError_t err = hipDeviceSynchronize();
                     if (err != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(err)); return 1; }
@@ -97,16 +99,16 @@ int main(int argc, char** argv) {
                 const int bad = check_columns(h, hs, out, fl, n, ns, C, ncols, ncheck, &nchecked);
                 const double bytes = 12.0 * n * ncols;
                 printf("n = %5ld ns = %5ld %-6s %8.1f us  %6.2f TB/s  %.3f of 8 TB/s   flagged %d, mismatches on %d checked columns %d\n", n, ns,
-                       kern ? "rank5" : "rank4", best * 1e3, bytes / (best * 1e9), bytes / (best * 1e9) / 8.0, nflag, nchecked, bad);
+                       kern == 2 ? "rank5w" : (kern ? "rank5" : "rank4"), best * 1e3, bytes / (best * 1e9), bytes / (best * 1e9) / 8.0, nflag, nchecked, bad);
                 fflush(stdout);
                 tot_us[kern] += weight[si] * best * 1e3;
                 if (kern == 0) tot_bytes += weight[si] * bytes;
             }
             hipFree(x); hipFree(out); hipFree(ss); hipFree(flags); hipFree(dlo); hipFree(dhi);
         }
-        for (int kern = 0; kern < 2; kern++)
+        for (int kern = 0; kern < 3; kern++)
             printf("schedule-weighted (13/12/10/9/8 iterations), ns = %s, %-6s: %.2f ms per step, %.2f TB/s = %.3f of HBM peak\n",
-                   ratio ? "23 n / 16" : "3 n / 4", kern ? "rank5" : "rank4", tot_us[kern] * 1e-3, tot_bytes / (tot_us[kern] * 1e6),
+                   ratio ? "23 n / 16" : "3 n / 4", kern == 2 ? "rank5w" : (kern ? "rank5" : "rank4"), tot_us[kern] * 1e-3, tot_bytes / (tot_us[kern] * 1e6),
                    tot_bytes / (tot_us[kern] * 1e6) / 8.0);
     }
     // ---- adversarial columns, rank5 only, every column checked: [distribution][n]
@@ -156,12 +158,14 @@ int main(int argc, char** argv) {
                     a.out = out; a.ldo = n; a.oss = (long)Cc * n; a.out_vec = 1;
                     a.flags = flags; a.inv_2nt = 1.0 / (2.0 * n); a.ncols = nc;
                     a.rng_lo = dlo; a.rng_hi = dhi;
-                    if (!optex::rank5_supported(a)) {
-                        printf("adversarial n = %5ld ns = %5ld dist %d: not supported\n", n, ns, dist);
+                    for (int kern = 1; kern < 3; kern++)
+                    if (kern == 1 ? !optex::rank5_supported(a) : !optex::rank5w_supported(a)) {
+                        printf("adversarial n = %5ld ns = %5ld dist %d %s: not supported\n", n, ns, dist, kern == 1 ? "rank5" : "rank5w");
                     } else {
                         hipMemset(flags, 0, nc * 4);
                         hipMemset(out, 0xff, h.size() * 4);
-                        optex::launch_rank5(a, nc, 0);
+                        if (kern == 1) optex::launch_rank5(a, nc, 0);
+                        else optex::launch_rank5w(a, nc, 0);
                         hipError_t err = hipDeviceSynchronize();
                         if (err != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(err)); return 1; }
                         std::vector<int> fl(nc);
@@ -170,8 +174,8 @@ int main(int argc, char** argv) {
                         int nchecked = 0;
                         // all columns: check_columns walks (k * 2731 + 17) % nc, a permutation for nc = 64
                         const int bad = check_columns(h, hs, out, fl, n, ns, Cc, nc, nc, &nchecked);
-                        printf("adversarial n = %5ld ns = %5ld dist %d: flagged %2d of %d, mismatches on %2d checked columns %d%s\n", n, ns, dist,
-                               nflag, nc, nchecked, bad, bad ? "   <-- WRONG" : "");
+                        printf("adversarial n = %5ld ns = %5ld dist %d %-6s: flagged %2d of %d, mismatches on %2d checked columns %d%s\n", n, ns, dist,
+                               kern == 1 ? "rank5" : "rank5w", nflag, nc, nchecked, bad, bad ? "   <-- WRONG" : "");
                     }
                     fflush(stdout);
                     hipFree(x); hipFree(out); hipFree(ss); hipFree(flags); hipFree(dlo); hipFree(dhi);
