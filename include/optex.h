@@ -24,6 +24,10 @@
  *    is (ld = B*H*W, seg_stride = H*W) or simply one segment of n = B*H*W.
  *  - "pixel-major" (layout = OPTEX_PIXEL_MAJOR) is the reference's NHWC-contiguous [n, C] layout:
  *    pixel i, channel c at  base + s*seg_stride + i*ld + c.
+ *  - `unsigned flags` (ABI 10; the argument in front of `stream` of the five entry points that launch the hot kernels):
+ *    per-CALL choices that ABI 8 / 9 kept in process-wide setters.  0 = the defaults.  They hold for this call only (and for
+ *    whatever it runs inside), on the calling thread only: two threads — two devices, two OptimalTexture objects — with
+ *    different choices do not see each other (re-entrant per call, no global mutable state).
  */
 #ifndef OPTEX_H
 #define OPTEX_H
@@ -35,11 +39,23 @@
 extern "C" {
 #endif
 
-#define OPTEX_ABI_VERSION 9
+#define OPTEX_ABI_VERSION 10
 #define OPTEX_BINS 256 /* histmatch.py:49 `bins: int = 256` (the only value any caller uses) */
 
 enum { OPTEX_OK = 0, OPTEX_E_ARG = -1, OPTEX_E_LAUNCH = -2, OPTEX_E_UNSUPPORTED = -3 };
 enum { OPTEX_CHANNEL_MAJOR = 0, OPTEX_PIXEL_MAJOR = 1 };
+
+/* flags (ABI 10) */
+#define OPTEX_F_DEFAULT 0u
+/* bits 0-7: the persistent R-stationary rotation GEMM leaves `n` of the CUs out of its grid (n <= 254; see optex_gemm_spare_cus
+ * below for why).  Not given: 1.  OPTEX_F_SPARE_CUS(0) = one workgroup on every CU. */
+#define OPTEX_F_SPARE_CUS(n) ((((unsigned)(n)) + 1u) & 0xffu)
+/* the cdf matcher as the two-kernel pipeline (cdf_hist_lut_kernel + cdf_apply_kernel) even where the one-kernel matcher with the
+ * column in registers would run — the same bits either way (tests/test_gpu_parity.py compares them) */
+#define OPTEX_F_CDF_TWO_KERNEL 0x100u
+/* the sort matcher on rank_match4_kernel (8-slot windows, rounds 2-5) even where rank_match5w_kernel (round 6: 8-bit buckets,
+ * keys alone in their bucket ranked without a window) would run — the same bits either way */
+#define OPTEX_F_SORT_RANK4 0x200u
 
 int optex_abi_version(void);
 const char* optex_last_error(void);
@@ -50,13 +66,16 @@ int optex_device_info(int* n_cu, int* lds_bytes, int* wavefront);
  * RCCL broadcast — then leaves one workgroup of every GEMM launch waiting for a CU: its tiles start when another workgroup has
  * finished, and the launch takes twice as long (measured at 8 textures per step: 46.3 ms per step against 43.8 without the
  * generator).  `spare` CUs are left out of the GEMM's grid (default 1: 0.4 % more work per workgroup, nothing to wait for);
- * 0 restores one workgroup on every CU.  Returns the previous value; process-wide, takes effect with the next launch. */
+ * 0 restores one workgroup on every CU.  Returns the previous value.
+ * DEPRECATED since ABI 10 (kept for one version): this moves the process-wide DEFAULT only — what a call without
+ * OPTEX_F_SPARE_CUS(n) in its flags gets; pass the choice with the call instead. */
 int optex_gemm_spare_cus(int spare);
 /* ABI 9.  optex_cdf_match / the cdf iteration of optex_ot_loop run range + histograms + LUT + interpolation of a column as ONE
  * kernel that keeps the column in registers (columns of at most 16384 values, 16-byte aligned rows, one workgroup per column:
  * every batched call of the hot loop) — the target is read from HBM once instead of twice.  `on` = 0 forces the two-kernel
  * pipeline (cdf_hist_lut_kernel + cdf_apply_kernel: what longer or chunked columns take anyway), the same bits either way
- * (tests/test_gpu_parity.py compares them).  Returns the previous value; process-wide, default 1. */
+ * (tests/test_gpu_parity.py compares them).  Returns the previous value; default 1.
+ * DEPRECATED since ABI 10 (kept for one version): the process-wide default of calls without OPTEX_F_CDF_TWO_KERNEL. */
 int optex_cdf_fused(int on);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -76,7 +95,7 @@ int optex_gemm_tn(const float* At, long lda, long at_seg_stride,
                   float* OUT, long ldo, long o_seg_stride, int o_layout,
                   int M, int K, long n, int n_seg,
                   const float* bsub, long bsub_seg_stride, const float* badd, long badd_seg_stride,
-                  const float* content, float strength, void* stream);
+                  const float* content, float strength, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K2/K3  cdf mode, histmatch.py:49-69 (cdf_match) + histmatch.py:72-92 (interp), 256 bins.
@@ -100,7 +119,7 @@ size_t optex_cdf_ws_bytes(int C, int n_seg);
 int optex_cdf_match(const float* target, long ldt, long t_seg_stride, long nt,
                     const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
                     int C, int n_seg, float* out, long ldo, long o_seg_stride,
-                    void* ws, size_t ws_bytes, float* dbg, void* stream);
+                    void* ws, size_t ws_bytes, float* dbg, unsigned flags, void* stream);
 
 /* histmatch.py:49 `cdf_match(target, source, bins)` with the bin count free (ABI 6).  Every caller inside the reference leaves
  * bins at 256 (optex_cdf_match above, the hot path); this entry serves a direct call with another value.  Same arguments and
@@ -125,7 +144,8 @@ size_t optex_sort_match_ws_bytes(long nt, long ns, int C, int n_seg, int src_n_s
  * target value of the column. */
 int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt,
                      const float* source, long lds, long s_seg_stride, long ns, int src_n_seg,
-                     int C, int n_seg, float* out, long ldo, long o_seg_stride, void* ws, size_t ws_bytes, void* stream);
+                     int C, int n_seg, float* out, long ldo, long o_seg_stride, void* ws, size_t ws_bytes, unsigned flags,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K4  linear modes, histmatch.py:16-22: per-(segment, channel) spatial mean and the centred covariance
@@ -225,7 +245,7 @@ size_t optex_ot_loop_ws_bytes(int mode, long n, long ns, int C, int n_seg, int s
                               int fuse_rotations, long r_seg_stride);
 int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
                   const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content, float strength,
-                  int fuse_rotations, void* ws, size_t ws_bytes, void* stream);
+                  int fuse_rotations, void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
 /* The same loop between the PCA projection and unprojection of optex.py:109-110,119-120 (ABI 7), the reference's
  * default (PCA on):   x = feat @ E;  [iterations];  feat = x @ E^T   with E = eigvecs [C_full, C].
@@ -241,7 +261,7 @@ int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, lon
 size_t optex_ot_loop_pca_ws_bytes(int mode, long n, long ns, int C, int C_full, int n_seg, int src_n_seg, int iters);
 int optex_ot_loop_pca(int mode, float* x_full, int C_full, const float* eig, const float* eig_t, long n, int n_seg,
                       const float* style, long ns, int src_n_seg, int C, const float* R32, const float* Rt32, int iters,
-                      const float* content, float strength, void* ws, size_t ws_bytes, void* stream);
+                      const float* content, float strength, void* ws, size_t ws_bytes, unsigned flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * N3  element-wise glue between the VGG convolutions, vgg.py:14-135: conv bias add, nn.ReLU,

@@ -7,11 +7,20 @@ import torch  # imported BEFORE the CDLL so the library binds to the HIP runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liboptex_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 CHANNEL_MAJOR, PIXEL_MAJOR = 0, 1
 
 _c = ctypes
-_P, _L, _I, _F, _SZ = _c.c_void_p, _c.c_long, _c.c_int, _c.c_float, _c.c_size_t
+_P, _L, _I, _F, _SZ, _U = _c.c_void_p, _c.c_long, _c.c_int, _c.c_float, _c.c_size_t, _c.c_uint
+
+# the `flags` word of ABI 10 (include/optex.h): per-call choices, 0 = defaults
+F_DEFAULT, F_CDF_TWO_KERNEL, F_SORT_RANK4 = 0, 0x100, 0x200
+
+
+def f_spare_cus(n: int) -> int:
+    """OPTEX_F_SPARE_CUS(n): the persistent rotation GEMM of THIS call leaves n CUs out of its grid"""
+    return (int(n) + 1) & 0xff
+
 
 # name -> (restype, argtypes); mirrors include/optex.h one to one (tests/test_abi.py checks the export list)
 SIGNATURES = {
@@ -20,18 +29,18 @@ SIGNATURES = {
     "optex_device_info": (_I, [_P, _P, _P]),
     "optex_gemm_spare_cus": (_I, [_I]),
     "optex_cdf_fused": (_I, [_I]),
-    "optex_gemm_tn": (_I, [_P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _I, _I, _I, _L, _I, _P, _L, _P, _L, _P, _F, _P]),
+    "optex_gemm_tn": (_I, [_P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _I, _I, _I, _L, _I, _P, _L, _P, _L, _P, _F, _U, _P]),
     "optex_col_minmax": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P]),
     "optex_col_histc": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _P]),
     "optex_interp": (_I, [_P, _L, _P, _P, _L, _P, _P]),
     "optex_cdf_ws_bytes": (_SZ, [_I, _I]),
-    "optex_cdf_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _P, _P]),
+    "optex_cdf_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _P, _U, _P]),
     "optex_cdf_bins_ws_bytes": (_SZ, [_I, _I, _I]),
     "optex_cdf_match_bins": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _I, _P, _L, _L, _P, _SZ, _P]),
     "optex_sort_ws_bytes": (_SZ, [_L, _I, _I]),
     "optex_sort_columns": (_I, [_P, _L, _L, _L, _I, _I, _P, _P, _P, _SZ, _P]),
     "optex_sort_match_ws_bytes": (_SZ, [_L, _L, _I, _I, _I]),
-    "optex_sort_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _P]),
+    "optex_sort_match": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P, _L, _L, _P, _SZ, _U, _P]),
     "optex_linear_stats_ws_bytes": (_SZ, [_L, _I, _I]),
     "optex_linear_stats": (_I, [_P, _L, _L, _L, _I, _I, _I, _F, _P, _P, _P, _SZ, _P]),
     "optex_chol_ld": (_I, [_I]),
@@ -48,9 +57,9 @@ SIGNATURES = {
     "optex_legacy_normals": (_I, [_P, _I, _L, _P, _L, _P, _SZ, _P]),
     "optex_rotations_from_normals": (_I, [_P, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "optex_ot_loop_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I, _L]),
-    "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _L, _I, _P, _F, _I, _P, _SZ, _P]),
+    "optex_ot_loop": (_I, [_I, _P, _L, _I, _P, _L, _I, _I, _P, _P, _L, _I, _P, _F, _I, _P, _SZ, _U, _P]),
     "optex_ot_loop_pca_ws_bytes": (_SZ, [_I, _L, _L, _I, _I, _I, _I, _I]),
-    "optex_ot_loop_pca": (_I, [_I, _P, _I, _P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _I, _P, _F, _P, _SZ, _P]),
+    "optex_ot_loop_pca": (_I, [_I, _P, _I, _P, _P, _L, _I, _P, _L, _I, _I, _P, _P, _I, _P, _F, _P, _SZ, _U, _P]),
     "optex_vgg_glue": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "optex_vgg_glue_layout": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "optex_prof_enable": (_I, [_I]),

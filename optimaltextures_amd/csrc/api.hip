@@ -7,6 +7,7 @@
 namespace optex {
 
 static thread_local char g_err[512] = "";
+thread_local CallOpts tl_call;
 
 void set_error(const char* fmt, ...) {
     va_list ap;

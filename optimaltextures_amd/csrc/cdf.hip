@@ -1064,7 +1064,7 @@ int cdf_match_parts_impl(const float* target, long ldt, long tss, long nt, const
     // each target segment's range (n_seg blocks per channel re-read it through L2) but comes from HBM once — and the 3 KB LUT
     // per column that reaches HBM (the histograms, CDFs and edges stay in LDS)
     const double hist_bytes = 4.0 * ((double)nt * ncols + (double)ns * C * src_n_seg) + 3.0 * 4 * kBins * ncols;
-    if (cdf_fused_enabled && blocks_y == 1 && vec && a.vec_t && nt % 4 == 0 && nt <= 16384 && ns <= 65536) {
+    if ((tl_call.cdf_two_kernel >= 0 ? tl_call.cdf_two_kernel == 0 : cdf_fused_enabled != 0) && blocks_y == 1 && vec && a.vec_t && nt % 4 == 0 && nt <= 16384 && ns <= 65536) {
         // the whole matcher in one launch, the column in registers: the target is read once and written once (KC_CDF_FUSED)
         if (tmn_parts) {   // the target's own range, one pair per column (joined with the source's inside the kernel)
             if ((rc = minmax_fold_parts(tmn_parts, tmx_parts, parts, C, ncols, w.lo, w.hi, st))) return rc;
@@ -1138,7 +1138,8 @@ extern "C" size_t optex_cdf_ws_bytes(int C, int n_seg) { return CdfWs::bytes(C, 
 
 extern "C" int optex_cdf_match(const float* target, long ldt, long t_seg_stride, long nt, const float* source, long lds,
                                long s_seg_stride, long ns, int src_n_seg, int C, int n_seg, float* out, long ldo,
-                               long o_seg_stride, void* ws, size_t ws_bytes, float* dbg, void* stream) {
+                               long o_seg_stride, void* ws, size_t ws_bytes, float* dbg, unsigned flags, void* stream) {
+    CallScope call_scope(flags);
     if (!target || !source || !out || !ws || nt <= 0 || ns <= 0 || C <= 0 || n_seg <= 0 || ldt < nt || lds < ns ||
         ldo < nt) {
         set_error("optex_cdf_match: bad argument (nt=%ld ns=%ld C=%d n_seg=%d)", nt, ns, C, n_seg);

@@ -623,7 +623,8 @@ extern "C" int optex_gemm_tn(const float* At, long lda, long at_seg_stride, cons
                              long b_seg_stride, int b_layout, float* OUT, long ldo, long o_seg_stride, int o_layout,
                              int M, int K, long n, int n_seg, const float* bsub, long bsub_seg_stride,
                              const float* badd, long badd_seg_stride, const float* content, float strength,
-                             void* stream) {
+                             unsigned flags, void* stream) {
+    CallScope call_scope(flags);
     if (!At || !B || !OUT || M <= 0 || K <= 0 || n < 0 || n_seg < 0) {
         set_error("optex_gemm_tn: null pointer or non-positive size (M=%d K=%d n=%ld n_seg=%d)", M, K, n, n_seg);
         return OPTEX_E_ARG;

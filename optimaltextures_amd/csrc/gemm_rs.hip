@@ -595,10 +595,12 @@ int gemm_rs_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
     const long per_group = (long)ra.tiles_n * ra.segs_per_group;
     // one workgroup per CU over all groups, minus the spare CUs (include/optex.h, optex_gemm_spare_cus: a workgroup needs a whole
     // CU, and a CU held by a small kernel of another stream would make it the launch's straggler)
-    int cus = n_cu - gemm_rs_spare_cus;
+    int cus = n_cu - (tl_call.spare_cus >= 0 ? tl_call.spare_cus : gemm_rs_spare_cus);
     if (cus < n_cu / 2) cus = n_cu / 2;
     if (cus < 1) cus = 1;
-    long gx = (cus + groups - 1) / groups;
+    // `cus` bounds the TOTAL grid: with several groups (per-segment matrices) the workgroups per group are rounded DOWN, or
+    // 64 groups x ceil(255 / 64) would be 256 workgroups again and the spare CU's straggler with them
+    long gx = groups <= cus ? cus / groups : 1;
     if (gx > per_group) gx = per_group;
     ProfScope prof(a.prof_cls, st, 2.0 * a.M * a.K * (double)a.n * a.n_seg,
                    4.0 * ((double)(a.K + a.M) * a.n * a.n_seg + (double)a.K * a.M));

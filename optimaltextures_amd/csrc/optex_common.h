@@ -20,6 +20,23 @@ int check_launch(const char* what);
 int check_ws(const char* fn, const void* ws, size_t have, size_t need);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Per-call options (the `flags` word of include/optex.h, ABI 10), held THREAD-LOCALLY for the duration of one extern "C" call:
+// the launchers underneath read them, an entry point called from inside another one (flags = 0) inherits the outer call's.
+// -1 = not given: the library default (for two of them a deprecated process-wide setter can still move the default).
+struct CallOpts { int spare_cus = -1, cdf_two_kernel = -1, sort_rank4 = -1; };
+extern thread_local CallOpts tl_call;
+struct CallScope {
+    CallOpts saved;
+    explicit CallScope(unsigned flags) : saved(tl_call) {
+        if (flags & 0xffu) tl_call.spare_cus = (int)(flags & 0xffu) - 1;
+        if (flags & OPTEX_F_CDF_TWO_KERNEL) tl_call.cdf_two_kernel = 1;
+        if (flags & OPTEX_F_SORT_RANK4) tl_call.sort_rank4 = 1;
+    }
+    ~CallScope() { tl_call = saved; }
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+};
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Bijective XCD-aware remap of a 1-D block id: consecutive logical ids land on the same XCD (and share its L2).

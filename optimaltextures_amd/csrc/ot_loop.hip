@@ -175,7 +175,7 @@ int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, 
     const long xs = (long)C * n;
     if (ldb == 0) ldb = n;
     return optex_gemm_tn(At, C, at_ss, B, ldb, (long)C * ldb, OPTEX_CHANNEL_MAJOR, O, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, bsub,
-                         C, badd, badd_ss, content, strength, stream);
+                         C, badd, badd_ss, content, strength, 0u, stream);
 }
 
 
@@ -473,18 +473,18 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
         int rc;
         if (iters > 1 &&
             (rc = optex_gemm_tn(R32, C, (long)C * C, R32 + (size_t)C * C, C, (long)C * C, OPTEX_CHANNEL_MAJOR, w.P, C,
-                                (long)C * C, OPTEX_CHANNEL_MAJOR, C, C, C, iters - 1, nullptr, 0, nullptr, 0, nullptr, 0.f,
+                                (long)C * C, OPTEX_CHANNEL_MAJOR, C, C, C, iters - 1, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u,
                                 stream)))
             return rc;
         float* cur = w.y;
         float* nxt = w.y2;
         if ((rc = optex_gemm_tn(R32, C, 0, x, n, xs, OPTEX_CHANNEL_MAJOR, cur, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
-                                nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
             return rc;
         for (int it = 0; it < iters; it++) {
             const float* R = R32 + (size_t)it * C * C;
             if ((rc = optex_gemm_tn(R, C, 0, style, ns, ss, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C, C,
-                                    ns, src_n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                    ns, src_n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
                 return rc;
             if (mode == MODE_CDF)
                 rc = cdf_match_impl(cur, n, xs, n, w.ys, ns, ss, ns, src_n_seg, C, n_seg, cur, n, xs, w.mode_ws, nullptr, st);
@@ -493,12 +493,12 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
             if (rc) return rc;
             if (it + 1 < iters) {  // straight into the next iteration's rotated frame
                 if ((rc = optex_gemm_tn(w.P + (size_t)it * C * C, C, 0, cur, n, xs, OPTEX_CHANNEL_MAJOR, nxt, n, xs,
-                                        OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                        OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
                     return rc;
                 float* t = cur; cur = nxt; nxt = t;
             } else {               // optex.py:175 of the last iteration
                 if ((rc = optex_gemm_tn(Rt32 + (size_t)it * C * C, C, 0, cur, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs,
-                                        OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                        OPTEX_CHANNEL_MAJOR, C, C, n, n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
                     return rc;
             }
         }
@@ -511,7 +511,7 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
         // matcher needs of each: its per-channel min / max (cdf, histmatch.py:52-53) or its sorted columns (sort), one
         // launch for all iterations.  Same arithmetic as inside the loop, 2-4 launches per CALL instead of per iteration.
         if ((rc = optex_gemm_tn(R32, C, (long)C * C, style, ns, 0, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss, OPTEX_CHANNEL_MAJOR, C,
-                                C, ns, iters, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                C, ns, iters, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
             return rc;
         if (mode == MODE_CDF) {
             // ... and its histogram over its own range: the joint range of histmatch.py:52-53 IS the style's range for every
@@ -538,7 +538,7 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
         const float* ys = w.hoist ? w.ys + (size_t)it * rs_seg * ss : w.ys;
         if (!w.hoist &&
             (rc = optex_gemm_tn(R, C, r_seg_stride, style, ns, src_n_seg > 1 ? ss : 0, OPTEX_CHANNEL_MAJOR, w.ys, ns, ss,
-                                OPTEX_CHANNEL_MAJOR, C, C, ns, rs_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                OPTEX_CHANNEL_MAJOR, C, C, ns, rs_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
             return rc;
         // optex.py:173  hist_match(rotated_pastiche, rotated_style), in place
         if (mode == MODE_CDF)
@@ -554,10 +554,10 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
         // optex.py:175 + 115-117  pastiche = matched @ rotation.T ; content blend
         if (fold && fold->xout && it == iters - 1)   // ... and the PCA unprojection rides in the last one: (E R_l)^T
             rc = optex_gemm_tn(fold->G, fold->Cf, 0, w.y, n, xs, OPTEX_CHANNEL_MAJOR, fold->xout, n, (long)fold->Cf * n,
-                               OPTEX_CHANNEL_MAJOR, fold->Cf, C, n, n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, stream);
+                               OPTEX_CHANNEL_MAJOR, fold->Cf, C, n, n_seg, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream);
         else
             rc = optex_gemm_tn(Rt, C, r_seg_stride, w.y, n, xs, OPTEX_CHANNEL_MAJOR, x, n, xs, OPTEX_CHANNEL_MAJOR, C, C, n, n_seg,
-                               nullptr, 0, nullptr, 0, content, strength, stream);
+                               nullptr, 0, nullptr, 0, content, strength, 0u, stream);
         if (rc) return rc;
     }
     return OPTEX_OK;
@@ -565,7 +565,8 @@ static int ot_loop_impl(int mode, float* x, long n, int n_seg, const float* styl
 
 extern "C" int optex_ot_loop(int mode, float* x, long n, int n_seg, const float* style, long ns, int src_n_seg, int C,
                              const float* R32, const float* Rt32, long r_seg_stride, int iters, const float* content,
-                             float strength, int fuse_rotations, void* ws, size_t ws_bytes, void* stream) {
+                             float strength, int fuse_rotations, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    CallScope call_scope(flags);
     return ot_loop_impl(mode, x, n, n_seg, style, ns, src_n_seg, C, R32, Rt32, r_seg_stride, iters, content, strength,
                         fuse_rotations, ws, ws_bytes, stream, nullptr);
 }
@@ -581,7 +582,8 @@ extern "C" size_t optex_ot_loop_pca_ws_bytes(int mode, long n, long ns, int C, i
 
 extern "C" int optex_ot_loop_pca(int mode, float* x_full, int C_full, const float* eig, const float* eig_t, long n, int n_seg,
                                  const float* style, long ns, int src_n_seg, int C, const float* R32, const float* Rt32, int iters,
-                                 const float* content, float strength, void* ws, size_t ws_bytes, void* stream) {
+                                 const float* content, float strength, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    CallScope call_scope(flags);
     if (!x_full || !eig || !eig_t || !style || (iters > 0 && (!R32 || !Rt32)) || !ws || n <= 0 || ns <= 0 || C < 2 || C_full < C ||
         n_seg <= 0 || iters < 0) {
         set_error("optex_ot_loop_pca: bad argument (n=%ld ns=%ld C=%d C_full=%d n_seg=%d iters=%d)", n, ns, C, C_full, n_seg, iters);
@@ -615,15 +617,15 @@ extern "C" int optex_ot_loop_pca(int mode, float* x_full, int C_full, const floa
     if (iters == 0) {
         // optex.py:110 then :120 with nothing in between: x_full <- (x_full @ E) @ E^T, the projector onto the kept subspace
         if ((rc = optex_gemm_tn(eig, C, 0, x_full, n, xfs, OPTEX_CHANNEL_MAJOR, xk, n, xs, OPTEX_CHANNEL_MAJOR, C, C_full, n, n_seg,
-                                nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
             return rc;
         return optex_gemm_tn(eig_t, C_full, 0, xk, n, xs, OPTEX_CHANNEL_MAJOR, x_full, n, xfs, OPTEX_CHANNEL_MAJOR, C_full, C, n, n_seg,
-                             nullptr, 0, nullptr, 0, nullptr, 0.f, stream);
+                             nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream);
     }
     // E R_0 as the [C_full, C] matrix of the first rotation: (E R_0)[c][m] = sum_j E[c][j] R_0[j][m] — the transposing GEMM reads
     // E as a "pixel-major" map of C_full pixels and stores the result pixel-major, i.e. row-major [C_full, C]
     if ((rc = optex_gemm_tn(R32, C, 0, eig, C, 0, OPTEX_PIXEL_MAJOR, ER0, C, 0, OPTEX_PIXEL_MAJOR, C, C, C_full, 1, nullptr, 0, nullptr,
-                            0, nullptr, 0.f, stream)))
+                            0, nullptr, 0.f, 0u, stream)))
         return rc;
     Fold f;
     f.xin = x_full;
@@ -635,7 +637,7 @@ extern "C" int optex_ot_loop_pca(int mode, float* x_full, int C_full, const floa
     if (fold_out) {
         // (E R_l)^T as the [C, C_full] matrix of the last rotation back: the same product stored channel-major
         if ((rc = optex_gemm_tn(R32 + (size_t)(iters - 1) * C * C, C, 0, eig, C, 0, OPTEX_PIXEL_MAJOR, G, C_full, 0,
-                                OPTEX_CHANNEL_MAJOR, C, C, C_full, 1, nullptr, 0, nullptr, 0, nullptr, 0.f, stream)))
+                                OPTEX_CHANNEL_MAJOR, C, C, C_full, 1, nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream)))
             return rc;
         f.xout = x_full;
         f.G = G;
@@ -645,5 +647,5 @@ extern "C" int optex_ot_loop_pca(int mode, float* x_full, int C_full, const floa
     if (fold_out) return OPTEX_OK;
     // optex.py:120  pastiche_feature @ eigvecs.T
     return optex_gemm_tn(eig_t, C_full, 0, xk, n, xs, OPTEX_CHANNEL_MAJOR, x_full, n, xfs, OPTEX_CHANNEL_MAJOR, C_full, C, n, n_seg,
-                         nullptr, 0, nullptr, 0, nullptr, 0.f, stream);
+                         nullptr, 0, nullptr, 0, nullptr, 0.f, 0u, stream);
 }

@@ -193,7 +193,11 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
         if ((rc = device_fill_u32(reinterpret_cast<uint32_t*>(flags), 0u, (size_t)ncols, st))) return rc;
         {
             ProfScope prof(MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH, st, 0.0, per_elem * (double)a.n * ncols);
-            if ((rc = launch_rank4(MODE, a, ncols, st))) return rc;  // owner-ranked, float domain (sort_rank4.hip)
+            // owner-ranked, float domain: over-provisioned 8-bit buckets where the shape allows it (sort_rank5.hip, round 6),
+            // the 8-slot-window kernel otherwise (sort_rank4.hip) — both flag what they cannot take
+            if (MODE == SORT_MATCH && tl_call.sort_rank4 <= 0 && rank5w_supported(a)) {
+                if ((rc = launch_rank5w(a, ncols, st))) return rc;
+            } else if ((rc = launch_rank4(MODE, a, ncols, st))) return rc;
         }
     }
     const size_t lds = (size_t)ITEMS * SORT_NT * 8 + (size_t)SORT_CSTR * SORT_NW * 4 + SORT_NW * 4;
@@ -307,7 +311,8 @@ extern "C" size_t optex_sort_match_ws_bytes(long nt, long ns, int C, int n_seg, 
 
 extern "C" int optex_sort_match(const float* target, long ldt, long t_seg_stride, long nt, const float* source,
                                 long lds, long s_seg_stride, long ns, int src_n_seg, int C, int n_seg, float* out,
-                                long ldo, long o_seg_stride, void* ws, size_t ws_bytes, void* stream) {
+                                long ldo, long o_seg_stride, void* ws, size_t ws_bytes, unsigned flags, void* stream) {
+    CallScope call_scope(flags);
     if (!target || !source || !out || !ws || nt <= 0 || ns <= 0 || C <= 0 || n_seg <= 0 || ldt < nt || lds < ns ||
         ldo < nt) {
         set_error("optex_sort_match: bad argument (nt=%ld ns=%ld C=%d n_seg=%d)", nt, ns, C, n_seg);

@@ -331,6 +331,7 @@ class OptimalTexture(torch.nn.Module):
         # texture then draws its own rotations — the batch equals B separate runs of the reference, seed for seed
         self.rng = None
         self.rng_next = None          # the NEXT call's DeviceNormals (begin_feed() done): fed during this call's codec phases
+        self.call_flags = 0            # further per-call flags of include/optex.h (ops.F_CDF_TWO_KERNEL, ops.F_SORT_RANK4), OR-ed in
         self.gemm_spare_cus = "auto"   # CUs the persistent rotation GEMM leaves free: "auto" (0 unless generator kernels may run beside an OT loop) or an int
 
     # -- optex.py:45-79, channel-major
@@ -528,19 +529,17 @@ class OptimalTexture(torch.nn.Module):
                 ev.record(torch.cuda.current_stream(pastiche.device))
                 nxt.feed_one(after=ev)
 
-        # The persistent rotation GEMM wants every CU whole (include/optex.h, optex_gemm_spare_cus): one CU is left out of its grid
+        # The persistent rotation GEMM wants every CU whole (include/optex.h, OPTEX_F_SPARE_CUS): one CU is left out of its grid
         # only when the generator's one-workgroup kernels may run beside an OT loop of this call — the un-gated prefetch above.
         # Draws that were fed during the previous call's codec phases (and this call's feeding of the next one) run beside
         # convolutions, which share a CU without harm.
         # (with a style_sync hook the later passes' RCCL broadcasts may still be in flight during the first loops: one CU stays free)
         crowded = ungated or (self.style_sync is not None and sides is not None)
         spare = (1 if crowded else 0) if self.gemm_spare_cus == "auto" else int(self.gemm_spare_cus)
-        prev_spare = ops.gemm_spare_cus(spare) if pastiche.is_cuda else None
-        try:
+        # per CALL, through the flags word of every library call of this forward() on this thread (ABI 10) — not a process-wide
+        # setter any more: two OptimalTexture objects on two threads / devices do not see each other's choice
+        with ops.call_flags(ops.f_spare_cus(spare) | int(self.call_flags)):
             return self._forward_passes(pastiche, styles, content, verbose, on_layer, sides, nxt, feed_next)
-        finally:
-            if prev_spare is not None:
-                ops.gemm_spare_cus(prev_spare)
 
     def _forward_passes(self, pastiche, styles, content, verbose, on_layer, sides, nxt, feed_next):
         for p in range(self.passes):

@@ -4,12 +4,39 @@ Layout vocabulary: a *segment tensor* is fp32 [S, C, n] — S independent textur
 per channel contiguous: exactly NCHW memory.  Strided views of it are passed through (ld, seg_stride) without copies.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CHANNEL_MAJOR, PIXEL_MAJOR, check, ptr, stream_ptr, workspace
+from ._lib import CHANNEL_MAJOR, PIXEL_MAJOR, F_CDF_TWO_KERNEL, F_DEFAULT, F_SORT_RANK4, check, f_spare_cus, ptr, stream_ptr, workspace
+
+_tls = threading.local()
+
+
+class call_flags:
+    """`with ops.call_flags(f_spare_cus(0) | F_CDF_TWO_KERNEL): ...` — the `flags` word (include/optex.h, ABI 10) of every
+    library call made inside the block BY THIS THREAD that does not pass `flags=` itself.  Nested blocks combine: the spare-CU
+    byte of the inner one replaces the outer one's if it gives one, the other bits add up.  Nothing process-wide is touched:
+    two OptimalTexture objects on two threads (two devices) run with their own choices."""
+
+    def __init__(self, flags: int):
+        self.flags = int(flags)
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "flags", F_DEFAULT)
+        spare = (self.flags & 0xff) or (self.prev & 0xff)
+        _tls.flags = ((self.flags | self.prev) & ~0xff) | spare
+        return self
+
+    def __exit__(self, *exc):
+        _tls.flags = self.prev
+        return False
+
+
+def _flags(flags):
+    return ctypes.c_uint(getattr(_tls, "flags", F_DEFAULT) if flags is None else int(flags))
 
 BINS = 256
 LOOP_MODES = {"cdf": 0, "sort": 1, "chol": 2, "pca": 3, "sym": 4}  # optex_ot_loop / optex_transfer_operator mode codes
@@ -49,10 +76,10 @@ class Seg:
 
 
 def gemm_tn(At, B, out, M, K, n, n_seg, *, lda, at_ss=0, ldb, b_ss, b_layout=CHANNEL_MAJOR, ldo, o_ss,
-            o_layout=CHANNEL_MAJOR, bsub=None, bsub_ss=0, badd=None, badd_ss=0, content=None, strength=0.0):
+            o_layout=CHANNEL_MAJOR, bsub=None, bsub_ss=0, badd=None, badd_ss=0, content=None, strength=0.0, flags=None):
     check(_lib.lib().optex_gemm_tn(ptr(At), lda, at_ss, ptr(B), ldb, b_ss, b_layout, ptr(out), ldo, o_ss, o_layout,
                                    M, K, n, n_seg, ptr(bsub), bsub_ss, ptr(badd), badd_ss, ptr(content),
-                                   ctypes.c_float(strength), stream_ptr()))
+                                   ctypes.c_float(strength), _flags(flags), stream_ptr()))
     return out
 
 
@@ -94,7 +121,7 @@ def interp(x, xp, fp):
     return out
 
 
-def cdf_match_seg(t: Seg, s: Seg, out: Seg = None, debug=False):
+def cdf_match_seg(t: Seg, s: Seg, out: Seg = None, debug=False, flags=None):
     lib = _lib.lib()
     assert t.C == s.C
     if out is None:
@@ -103,7 +130,7 @@ def cdf_match_seg(t: Seg, s: Seg, out: Seg = None, debug=False):
     ws = workspace(lib.optex_cdf_ws_bytes(t.C, t.S), t.t.device)
     dbg = torch.empty((t.S, t.C, 2 + 4 * BINS), dtype=torch.float32, device=t.t.device) if debug else None
     check(lib.optex_cdf_match(ptr(t.t), t.ld, t.ss, t.n, ptr(s.t), s.ld, s.ss, s.n, s.S, t.C, t.S, ptr(out.t), out.ld,
-                              out.ss, ptr(ws), ws.numel(), ptr(dbg), stream_ptr()))
+                              out.ss, ptr(ws), ws.numel(), ptr(dbg), _flags(flags), stream_ptr()))
     if debug:
         d = dict(lo=dbg[..., 0], hi=dbg[..., 1], hist_t=dbg[..., 2:2 + BINS], hist_s=dbg[..., 2 + BINS:2 + 2 * BINS],
                  bin_edges=dbg[..., 2 + 2 * BINS:2 + 3 * BINS], remapped=dbg[..., 2 + 3 * BINS:])
@@ -133,14 +160,14 @@ def sort_columns(x, want_keys=True, want_idx=True):
     return ok, oi
 
 
-def sort_match_seg(t: Seg, s: Seg, out: Seg = None):
+def sort_match_seg(t: Seg, s: Seg, out: Seg = None, flags=None):
     lib = _lib.lib()
     assert t.C == s.C
     if out is None:
         out = Seg.of(torch.empty((t.S, t.C, t.n), dtype=torch.float32, device=t.t.device))
     ws = workspace(lib.optex_sort_match_ws_bytes(t.n, s.n, t.C, t.S, s.S), t.t.device)
     check(lib.optex_sort_match(ptr(t.t), t.ld, t.ss, t.n, ptr(s.t), s.ld, s.ss, s.n, s.S, t.C, t.S, ptr(out.t), out.ld,
-                               out.ss, ptr(ws), ws.numel(), stream_ptr()))
+                               out.ss, ptr(ws), ws.numel(), _flags(flags), stream_ptr()))
     return out.t
 
 
@@ -216,7 +243,7 @@ def rotations_from_normals(normals, N, count, device, want64=False):
     return (R32, Rt32, R64) if want64 else (R32, Rt32)
 
 
-def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False):
+def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotations=False, flags=None):
     """optex.py:112-117, all iterations enqueued by one C call, for every hist_mode; x [S, C, n] (independent segments) is
     updated IN PLACE.  R32 / Rt32: [iters, C, C] shared by all segments (the reference shares R across its batch), or
     [S, iters, C, C]: one rotation set per segment.  fuse_rotations = True / 1 (labelled fast paths, fp32
@@ -245,11 +272,11 @@ def ot_loop(mode, x, style, R32, Rt32, content=None, strength=0.0, fuse_rotation
         fuse = 0
     ws = workspace(lib.optex_ot_loop_ws_bytes(m, n, ns, C, S, Ss, iters, fuse, r_ss), x.device)
     check(lib.optex_ot_loop(m, ptr(_f32c(x)), n, S, ptr(_f32c(style)), ns, Ss, C, ptr(R32), ptr(Rt32), r_ss, iters,
-                            ptr(content), ctypes.c_float(strength), fuse, ptr(ws), ws.numel(), stream_ptr()))
+                            ptr(content), ctypes.c_float(strength), fuse, ptr(ws), ws.numel(), _flags(flags), stream_ptr()))
     return x
 
 
-def ot_loop_pca(mode, x_full, eigvecs, eigvecs_t, style, R32, Rt32, content=None, strength=0.0):
+def ot_loop_pca(mode, x_full, eigvecs, eigvecs_t, style, R32, Rt32, content=None, strength=0.0, flags=None):
     """optex.py:110 -> 112-117 -> 120 in one C call: x_full [S, C_full, n] un-projected features, updated IN PLACE; eigvecs
     [C_full, k] and its transpose; style [Ss, k, ns] and content (None or [S, k, n]) projected already; R32 / Rt32 [iters, k, k].
     The projection rides in the first rotation and (cdf / sort, no content) the unprojection in the last (optex_ot_loop_pca)."""
@@ -265,7 +292,7 @@ def ot_loop_pca(mode, x_full, eigvecs, eigvecs_t, style, R32, Rt32, content=None
     ws = workspace(lib.optex_ot_loop_pca_ws_bytes(m, n, ns, C, Cf, S, Ss, iters), x_full.device)
     check(lib.optex_ot_loop_pca(m, ptr(_f32c(x_full)), Cf, ptr(_f32c(eigvecs)), ptr(_f32c(eigvecs_t)), n, S, ptr(_f32c(style)), ns, Ss,
                                 C, ptr(R32), ptr(Rt32), iters, ptr(content), ctypes.c_float(strength), ptr(ws), ws.numel(),
-                                stream_ptr()))
+                                _flags(flags), stream_ptr()))
     return x_full
 
 
@@ -316,13 +343,13 @@ def profile_collect():
 
 
 def gemm_spare_cus(spare: int) -> int:
-    """CUs the persistent rotation GEMM leaves out of its grid (include/optex.h, optex_gemm_spare_cus; default 1: a small kernel
-    of another stream — the rotation generator, an RCCL broadcast — then never makes one of its workgroups wait for a CU).
+    """DEPRECATED (ABI 10): the process-wide DEFAULT of the CUs the persistent rotation GEMM leaves out of its grid — what a call
+    without f_spare_cus(n) in its flags gets (include/optex.h, optex_gemm_spare_cus).  Use `flags=` / `ops.call_flags`.
     Returns the previous value."""
     return int(_lib.load().optex_gemm_spare_cus(int(spare)))
 
 
 def cdf_fused(on: bool) -> bool:
-    """The cdf matcher as ONE kernel that keeps each column in registers (include/optex.h, optex_cdf_fused; default on) or as the
-    two-kernel pipeline (histograms + LUT, then the interpolation).  The same bits either way.  Returns the previous setting."""
+    """DEPRECATED (ABI 10): the process-wide default of calls without F_CDF_TWO_KERNEL (include/optex.h, optex_cdf_fused).  Use
+    `flags=F_CDF_TWO_KERNEL` / `ops.call_flags`.  Returns the previous setting."""
     return bool(_lib.load().optex_cdf_fused(1 if on else 0))
