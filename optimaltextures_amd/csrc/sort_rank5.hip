@@ -81,6 +81,7 @@ __device__ __forceinline__ unsigned r5_wave_incl_scan(unsigned v) {
 #define R5_STAMP(i) do { } while (0)
 #endif
 
+#ifdef R5_PERSISTENT_VARIANT  // the one-workgroup-per-CU experiment: probe builds only (scripts/sort5_probe.hip), not in the library
 #ifndef R5_G
 #define R5_G 8   // keys whose LDS operations are in flight together in the count / decode steps
 #endif
@@ -538,8 +539,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 int device_cu_count();
 
 // ---------------------------------------------------------------------------------------------------------------------------
+#endif  // R5_PERSISTENT_VARIANT
+
 #ifndef R5W_H16
-#define R5W_H16 4
+#define R5W_H16 4   // mates read together at 14 .. 16 keys per thread (8 below)
+#endif
+#ifndef R5W_G
+#define R5W_G 4     // keys whose LDS operations are in flight together in the count and decode steps
 #endif
 // rank_match5w_kernel: the same ranking step at a 64-register budget, ONE column per workgroup, TWO (or more) workgroups per CU
 // like rank_match4_kernel — the counters shrink to three buckets per key (NWRD = 12 * NT words at 13 .. 16 keys per thread:
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     // ---- 3. fine bucket + returning count atomic.  st[r] = b | arrival << 16
     uint32_t st[ITEMS];
-    constexpr int G = ITEMS < 4 ? ITEMS : 4;
+    constexpr int G = ITEMS < R5W_G ? ITEMS : R5W_G;
 #pragma unroll
     for (int g = 0; g < ITEMS; g += G) {
         float fr[G];
@@ -868,7 +874,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             st[r] += (m1[k] < x[r]) ? 1u : 0u;
             tie |= (m1[k] == x[r]) ? (1u << r) : 0u;
         }
-        asm volatile("" ::: "memory");
+        // (this group's ranks are final HERE: left to itself the compiler sinks every group's compares to the end of the step,
+        // keeps all the mates alive until then and spills them — one ds_read + s_waitcnt + scratch_store per key)
+#pragma unroll
+        for (int k = 0; k < H; k++)
+            if (h + k < ITEMS) asm volatile("" : "+v"(st[h + k]));
+        asm volatile("" : "+v"(tie)::"memory");
     }
     if (tie != 0u) {
         const int tt = otid();
@@ -959,7 +970,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (valid(r)) o[r * NT + to] = v[r];
 }
 
-static int rank5w_threads(long n) { return n > 5120 ? 1024 : 512; }
+// 6400 keys (a pass size of the 512^2 schedule) fill 640 threads x 10 keys exactly, three workgroups to a CU (as in sort_rank4.hip)
+static int rank5w_threads(long n) { return n == 6400 ? 640 : (n > 5120 ? 1024 : 512); }
 
 bool rank5w_supported(const SortArgs& a) {
     if (!a.rng_lo || !a.rng_hi || !a.src_sorted || !a.out) return false;
@@ -1023,9 +1035,14 @@ static int launch_rank5w_nt(const SortArgs& a, int ncols, hipStream_t st) {
 }
 
 int launch_rank5w(const SortArgs& a, int ncols, hipStream_t st) {
-    return rank5w_threads(a.n) == 512 ? launch_rank5w_nt<512>(a, ncols, st) : launch_rank5w_nt<1024>(a, ncols, st);
+    switch (rank5w_threads(a.n)) {
+        case 512: return launch_rank5w_nt<512>(a, ncols, st);
+        case 640: return launch_rank5w_items<10, 640>(a, ncols, st);
+        default: return launch_rank5w_nt<1024>(a, ncols, st);
+    }
 }
 
+#ifdef R5_PERSISTENT_VARIANT
 // Workgroup shape by column length: one 1024-thread workgroup per CU above 8192 keys, two of 512 threads down to 4097, four
 // of 256 below — always 16 wavefronts per CU at a 128-register budget, 9 .. 16 keys per thread (8 .. 16 with 256 threads).
 static int rank5_threads(long n) { return n > 8192 ? 1024 : (n > 4096 ? 512 : 256); }
@@ -1096,5 +1113,7 @@ int launch_rank5(const SortArgs& a, int ncols, hipStream_t st) {
         default: return launch_rank5_nt<1024>(a, ncols, st);
     }
 }
+
+#endif  // R5_PERSISTENT_VARIANT
 
 }  // namespace optex

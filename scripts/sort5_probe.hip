@@ -77,14 +77,20 @@ int main(int argc, char** argv) {
             hipEventCreate(&e0); hipEventCreate(&e1);
             for (int kern = 0; kern < 3; kern++) {
                 if (kern == 2 && !optex::rank5w_supported(a)) { printf("n = %5ld ns = %5ld rank5w: not supported\n", n, ns); continue; }
+#ifdef R5_PERSISTENT_VARIANT
                 if (kern == 1 && !optex::rank5_supported(a)) { printf("n = %5ld ns = %5ld rank5: not supported\n", n, ns); continue; }
+#else
+                if (kern == 1) continue;  // the one-workgroup-per-CU experiment: sort5_probe_persist.bin
+#endif
                 float best = 1e30f, ms = 0.f;
                 for (int it = 0; it < reps + 1; it++) {
                     hipMemset(flags, 0, ncols * 4);
                     hipMemset(out, 0xff, h.size() * 4);
                     hipEventRecord(e0, 0);
                     if (kern == 0) optex::launch_rank4(optex::SORT_MATCH, a, ncols, 0);
+#ifdef R5_PERSISTENT_VARIANT
                     else if (kern == 1) optex::launch_rank5(a, ncols, 0);
+#endif
                     else optex::launch_rank5w(a, ncols, 0);
                     hipEventRecord(e1, 0);
                     hipError_t err = hipDeviceSynchronize();
@@ -107,6 +113,7 @@ int main(int argc, char** argv) {
             hipFree(x); hipFree(out); hipFree(ss); hipFree(flags); hipFree(dlo); hipFree(dhi);
         }
         for (int kern = 0; kern < 3; kern++)
+            if (tot_us[kern] > 0)
             printf("schedule-weighted (13/12/10/9/8 iterations), ns = %s, %-6s: %.2f ms per step, %.2f TB/s = %.3f of HBM peak\n",
                    ratio ? "23 n / 16" : "3 n / 4", kern == 2 ? "rank5w" : (kern ? "rank5" : "rank4"), tot_us[kern] * 1e-3, tot_bytes / (tot_us[kern] * 1e6),
                    tot_bytes / (tot_us[kern] * 1e6) / 8.0);
@@ -158,14 +165,22 @@ int main(int argc, char** argv) {
                     a.out = out; a.ldo = n; a.oss = (long)Cc * n; a.out_vec = 1;
                     a.flags = flags; a.inv_2nt = 1.0 / (2.0 * n); a.ncols = nc;
                     a.rng_lo = dlo; a.rng_hi = dhi;
+#ifdef R5_PERSISTENT_VARIANT
                     for (int kern = 1; kern < 3; kern++)
                     if (kern == 1 ? !optex::rank5_supported(a) : !optex::rank5w_supported(a)) {
+#else
+                    for (int kern = 2; kern < 3; kern++)
+                    if (!optex::rank5w_supported(a)) {
+#endif
                         printf("adversarial n = %5ld ns = %5ld dist %d %s: not supported\n", n, ns, dist, kern == 1 ? "rank5" : "rank5w");
                     } else {
                         hipMemset(flags, 0, nc * 4);
                         hipMemset(out, 0xff, h.size() * 4);
+#ifdef R5_PERSISTENT_VARIANT
                         if (kern == 1) optex::launch_rank5(a, nc, 0);
-                        else optex::launch_rank5w(a, nc, 0);
+                        else
+#endif
+                        optex::launch_rank5w(a, nc, 0);
                         hipError_t err = hipDeviceSynchronize();
                         if (err != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(err)); return 1; }
                         std::vector<int> fl(nc);

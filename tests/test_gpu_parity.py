@@ -288,16 +288,17 @@ def test_cdf_match_fused_kernel_equals_two_kernel_pipeline_and_oracle(dev, nt, n
             # Segment 1 holds the stated deviation, asserted explicitly: the oracle takes torch.min / max literally, so
             # a NaN in a column makes its joint range NaN and the whole column NaN (histmatch.py:52-53), an inf makes it inf; the
             # kernels drop NaN from the range.  Both kernels agree with each other everywhere (above) and with the oracle in
-            # every OTHER column of the segment, bit for bit; in the NaN column the finite values are matched (finite, inside the
-            # source's range) and exactly the NaN positions stay NaN.
+            # every OTHER column of the segment, bit for bit; in the NaN column the finite values are matched as if the NaN values
+            # were not there; what a NaN VALUE itself maps to is unspecified (both kernels give the same bits, above).
             for c in range(C):
                 if c not in (2, 3):
                     assert biteq(o[k, c], want[c]), f"segment 1 column {c}"
             assert np.isnan(want[2]).all() and np.isinf(want[3]).all()
             nanpos = np.isnan(t[1, 2])
-            assert np.array_equal(np.isnan(o[1, 2]), nanpos)
             src = s[1 if Ss > 1 else 0, 2]
-            assert np.isfinite(o[1, 2][~nanpos]).all() and o[1, 2][~nanpos].min() >= src.min() and o[1, 2][~nanpos].max() <= src.max()
+            # ... i.e. they are what the reference's arithmetic gives for the column WITHOUT its NaN values (same range, same
+            # counts, same normalisation by the number of counted values), bit for bit
+            assert biteq(o[1, 2][~nanpos], orc.cdf_match(t[1, 2][~nanpos][None], src[None])[0])
 
 
 # ================================================================================================ K6 sort mode
