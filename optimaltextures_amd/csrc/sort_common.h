@@ -42,6 +42,8 @@ struct SortArgs {
     // optional, rank_match4_kernel: the column's min / max [ncols] when the caller has them already (optex_ot_loop: the
     // rotation GEMM's row-statistics epilogue) — the kernel then skips its own reduction and the barrier behind it
     const float* rng_lo; const float* rng_hi;
+    // rank_match5w_kernel: the quantile index floor((2 rank + 1) ns / (2 n)) as a multiply-high (sort_rank5.hip, quantile_magic)
+    unsigned qmul; int qshr;
 #ifdef OPTEX_SORT_PROBE
     long long* probe;                                         // [ncols, 16] phase timestamps (scripts/sort_phase_probe.hip)
 #endif

@@ -544,6 +544,9 @@ int device_cu_count();
 #ifndef R5W_H16
 #define R5W_H16 4   // mates read together at 14 .. 16 keys per thread (8 below)
 #endif
+#ifndef R5W_BRANCHFREE
+#define R5W_BRANCHFREE 0   // 1: place / mate steps without exec-mask branches (selects + a +inf word): measured SLOWER (profiles/r06_sort_experiments.md)
+#endif
 #ifndef R5W_G
 #define R5W_G 4     // keys whose LDS operations are in flight together in the count and decode steps
 #endif
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int j = 0; j < QR; j++) R5_LDS(r5_v4u, CW_B + (uint32_t)(j * NT + tz) * 16u) = r5_v4u{0u, 0u, 0u, 0u};
     }
     if (tid < RK_COARSE) c1[tid] = 0u;
-    if (tid < 32) misc[tid] = 0u;
+    if (tid < 32) misc[tid] = tid >= 28 ? R5_INF : 0u;  // words 28 .. 31: +inf, what a key without that mate reads
     if (!(hi < __uint_as_float(R5_INF)) || !(lo > -__uint_as_float(R5_INF))) {  // non-finite range: radix kernel
         if (tid == 0) a.flags[col] = 1;
         return;
@@ -734,8 +737,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
         for (int j = 0; j < G; j++) {
             if (g + j >= ITEMS) continue;
-            const uint32_t arr = __builtin_amdgcn_alignbyte(0u, old[j], b[j]) & 255u;
-            st[g + j] = b[j] | (arr << 16);
+            // byte b & 3 of the old word in bits 16 .. 23; what alignbyte leaves above it goes to bits 24 .. 31, which step 5 overwrites
+            st[g + j] = b[j] | (__builtin_amdgcn_alignbyte(0u, old[j], b[j]) << 16);
         }
 #pragma unroll
         for (int j = 0; j < G; j++)
@@ -785,8 +788,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
         for (int j = 0; j < G; j++) {
             if (g + j >= ITEMS) continue;
-            cw[j] = R5_LDS(const uint32_t, CW_B + (st[g + j] & 0xfffcu));
-            gs[j] = R5_LDS(const unsigned short, GS_B + ((st[g + j] >> 1) & 0x7ffeu));
+            const uint32_t wo = st[g + j] & 0xfffcu;  // byte offset of counter word b >> 2; half of it: of its 16-bit group start
+            cw[j] = R5_LDS(const uint32_t, CW_B + wo);
+            gs[j] = R5_LDS(const unsigned short, GS_B + (wo >> 1));
         }
 #pragma unroll
         for (int j = 0; j < G; j++) {
@@ -803,6 +807,92 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         asm volatile("" ::: "memory");
     }
     __syncthreads();  // B5
+#if R5W_BRANCHFREE
+    // ---- 6. place the keys that share a bucket.  No branches: a key alone in its bucket writes a per-lane dummy word (the
+    //         dead coarse histogram) — one select instead of an exec-mask round trip and a branch per key
+    {
+        const uint32_t dummy = C1_B + ((uint32_t)lane << 2);
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t pos = (st[r] & 0xffffu) + ((st[r] >> 16) & 255u);
+            const uint32_t addr = st[r] >= (2u << 24) ? SLOT_B + (pos << 2) : dummy;
+            R5_LDS(float, addr) = x[r];
+        }
+    }
+    __syncthreads();  // B6
+    // ---- 7. mates.  A key with cnt >= 2 reads its first mate (slot 0, or slot 1 for arrival 0), with cnt >= 3 its second (slot 2,
+    //         or slot 1 for arrivals 2 and up); every other key reads +inf from a fixed word (one address for all of them: a
+    //         broadcast): both reads of every key of a group in flight, no branch.  Equal mates (exact ties, -0 / +0) are noticed
+    //         in a scalar lane mask — v_cmp_eq into an SGPR pair, s_or — and sorted out by the lanes it names afterwards.
+    //         Buckets of four and more keys (0.2 % of the keys) recount their whole bucket.
+    uint32_t tie = 0u;  // bit r: key r has an equal bucket mate (set in the rare paths only)
+    constexpr int H = ITEMS < 8 ? ITEMS : (ITEMS > 13 ? R5W_H16 : 8);
+    constexpr uint32_t INF_B = MISC_B + 28u * 4u;
+#pragma unroll
+    for (int h = 0; h < ITEMS; h += H) {
+        float m1[H], m2[H];
+        uint32_t res[H];
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const int r = h + k;
+            if (r >= ITEMS) continue;
+            const uint32_t start = st[r] & 0xffffu;
+            const uint32_t a1 = start + ((st[r] & 0x00ff0000u) == 0u ? 1u : 0u);
+            const uint32_t a2 = start + ((st[r] & 0x00fe0000u) != 0u ? 1u : 2u);
+            m1[k] = R5_LDS(const float, st[r] >= (2u << 24) ? SLOT_B + (a1 << 2) : INF_B);
+            m2[k] = R5_LDS(const float, st[r] >= (3u << 24) ? SLOT_B + (a2 << 2) : INF_B);
+        }
+        unsigned long long eqm = 0ull;  // lanes whose key of this group has an equal mate
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            const int r = h + k;
+            if (r >= ITEMS) continue;
+            res[k] = st[r] + ((m1[k] < x[r]) ? 1u : 0u) + ((m2[k] < x[r]) ? 1u : 0u);
+            eqm |= __builtin_amdgcn_fcmpf(m1[k], x[r], 1) | __builtin_amdgcn_fcmpf(m2[k], x[r], 1);  // FCMP_OEQ
+        }
+        unsigned long long big = 0ull;
+#pragma unroll
+        for (int k = 0; k < H; k++)
+            if (h + k < ITEMS) big |= __builtin_amdgcn_uicmp(st[h + k], 4u << 24, 35);  // ICMP_UGE: cnt >= 4
+        if ((big | eqm) != 0ull) {  // uniform, rare per group: recount the whole bucket of the keys concerned (start still intact in st)
+            const bool mine = (((big | eqm) >> lane) & 1ull) != 0ull;
+#pragma unroll
+            for (int k = 0; k < H; k++) {
+                const int r = h + k;
+                if (r >= ITEMS) continue;
+                if (mine && st[r] >= (2u << 24)) {
+                    const uint32_t start = st[r] & 0xffffu, cnt = st[r] >> 24;
+                    uint32_t lt = 0u, eq = 0u;
+                    for (uint32_t j = 0; j < cnt; j += 4u) {
+                        float mm[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            mm[i] = __uint_as_float(R5_INF);
+                            if (j + (uint32_t)i < cnt) mm[i] = R5_LDS(const float, SLOT_B + ((start + j + (uint32_t)i) << 2));
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            lt += (mm[i] < x[r]) ? 1u : 0u;
+                            eq += (mm[i] == x[r]) ? 1u : 0u;
+                        }
+                    }
+                    res[k] = (start + lt) | (1u << 24);  // (cnt := 1: bit 31 must stay clear for the tie tag; eq counts the key itself once)
+                    tie |= eq > 1u ? (1u << r) : 0u;
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        // (this group's ranks are final HERE: left to itself the compiler sinks every group's compares to the end of the step,
+        // keeps all the mates alive until then and spills them)
+#pragma unroll
+        for (int k = 0; k < H; k++) {
+            if (h + k >= ITEMS) continue;
+            st[h + k] = res[k];
+            asm volatile("" : "+v"(st[h + k]));
+        }
+        asm volatile("" : "+v"(tie)::"memory");
+    }
+#else
     // ---- 6. place the keys that share a bucket
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -881,6 +971,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (h + k < ITEMS) asm volatile("" : "+v"(st[h + k]));
         asm volatile("" : "+v"(tie)::"memory");
     }
+#endif
     if (tie != 0u) {
         const int tt = otid();
         auto elem = [&](int r) { return r < 4 * Q ? ((r >> 2) * NT + tt) * 4 + (r & 3) : r * NT + tt; };
@@ -948,10 +1039,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int r = 0; r < ITEMS; r++) {
             const unsigned rr = ragged(r) ? (valid(r) ? (st[r] & 0xffffu) : 0u) : (st[r] & 0xffffu);
             unsigned qi = rr;
-            if (!decltype(same)::value) {
-                const double aa = (double)(2u * rr + 1u) * (double)ns;
-                qi = (unsigned)__builtin_fma(aa, a.inv_2nt, 7.450580596923828e-09);
-            }
+            if (!decltype(same)::value)  // floor((2 rank + 1) ns / (2 n)), exact: launch_rank5w's multiplier (below)
+                qi = __umulhi(__umul24(rr, 2u * ns) + ns, a.qmul) >> a.qshr;
             v[r] = R5_LDS(const float, GS_B + (qi << 2));
             if ((r & 3) == 3) asm volatile("" ::: "memory");
         }
@@ -989,8 +1078,21 @@ bool rank5w_supported(const SortArgs& a) {
     return true;
 }
 
+// floor(A / d) for every A < 2^30 as (A * m) >> (30 + l) with l = ceil(log2 d), m = ceil(2^(30 + l) / d) < 2^32 (Granlund &
+// Montgomery 1994, Theorem 4.2 for 30-bit dividends: 2^(30+l) <= m d <= 2^(30+l) + 2^l).  Here d = 2 n and
+// A = (2 rank + 1) ns <= 32767 * 18432 < 2^30:  quantile index = umulhi(A, qmul) >> qshr,  qshr = l - 2.
+static void quantile_magic(SortArgs& a) {
+    const unsigned long long d = 2ull * (unsigned long long)a.n;
+    int l = 0;
+    while ((1ull << l) < d) l++;
+    a.qmul = (unsigned)(((1ull << (30 + l)) + d - 1ull) / d);
+    a.qshr = l - 2;
+}
+
 template <int ITEMS, int NT>
-static int launch_rank5w_items(const SortArgs& a, int ncols, hipStream_t st) {
+static int launch_rank5w_items(const SortArgs& a0, int ncols, hipStream_t st) {
+    SortArgs a = a0;
+    quantile_magic(a);
     const size_t lds = R5W<ITEMS, NT>::LDS;
     const bool full = a.n == (long)ITEMS * NT;
     auto go = [&](auto kern, DeviceOnce& once) {
