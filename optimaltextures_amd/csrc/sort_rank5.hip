@@ -826,7 +826,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     //         in a scalar lane mask — v_cmp_eq into an SGPR pair, s_or — and sorted out by the lanes it names afterwards.
     //         Buckets of four and more keys (0.2 % of the keys) recount their whole bucket.
     uint32_t tie = 0u;  // bit r: key r has an equal bucket mate (set in the rare paths only)
-    constexpr int H = ITEMS < 8 ? ITEMS : (ITEMS > 13 ? R5W_H16 : 8);
+    constexpr int H = ITEMS <= 8 ? (ITEMS < 4 ? ITEMS : 4) : (ITEMS > 13 ? R5W_H16 : 8);  // (one group of eight at eight keys per thread spills)
     constexpr uint32_t INF_B = MISC_B + 28u * 4u;
 #pragma unroll
     for (int h = 0; h < ITEMS; h += H) {
@@ -904,10 +904,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     __syncthreads();  // B6
     // ---- 7. mates, eight keys at a time (register budget)
     uint32_t tie = 0u;
-    constexpr int H = ITEMS < 8 ? ITEMS : (ITEMS > 13 ? R5W_H16 : 8);
+    constexpr int H = ITEMS <= 8 ? (ITEMS < 4 ? ITEMS : 4) : (ITEMS > 13 ? R5W_H16 : 8);  // (one group of eight at eight keys per thread spills)
 #pragma unroll
     for (int h = 0; h < ITEMS; h += H) {
         float m1[H];
+        uint32_t res[H];   // the group's ranks: st keeps the bucket starts until the end of the group (the tie recount needs them)
+        uint32_t eqc = 0u; // equal mates seen by this lane in this group (exact ties, -0 / +0): v_cmp_eq + v_addc per compare
 #pragma unroll
         for (int k = 0; k < H; k++) {
             const int r = h + k;
@@ -954,21 +956,38 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 const uint32_t j2 = (st[r] & 0x00fe0000u) != 0u ? 1u : 2u;
                 m1[k] = R5_LDS(const float, SLOT_B + ((start + j2) << 2));
             }
-            st[r] += (mm < x[r]) ? 1u : 0u;
-            tie |= (mm == x[r]) ? (1u << r) : 0u;
+            res[k] = st[r] + ((mm < x[r]) ? 1u : 0u);
+            eqc += (mm == x[r]) ? 1u : 0u;
         }
 #pragma unroll
         for (int k = 0; k < H; k++) {
             const int r = h + k;
             if (r >= ITEMS) continue;
-            st[r] += (m1[k] < x[r]) ? 1u : 0u;
-            tie |= (m1[k] == x[r]) ? (1u << r) : 0u;
+            res[k] += (m1[k] < x[r]) ? 1u : 0u;
+            eqc += (m1[k] == x[r]) ? 1u : 0u;
+        }
+        if (__any(eqc != 0u)) {  // rare (a tie or two per column): which keys of the lane it was — the whole bucket again
+#pragma unroll
+            for (int k = 0; k < H; k++) {
+                const int r = h + k;
+                if (r >= ITEMS) continue;
+                if (eqc != 0u && st[r] >= (2u << 24)) {
+                    const uint32_t start = st[r] & 0xffffu, cnt = st[r] >> 24;
+                    uint32_t eq = 0u;
+                    for (uint32_t j = 0; j < cnt; j++) eq += (R5_LDS(const float, SLOT_B + ((start + j) << 2)) == x[r]) ? 1u : 0u;
+                    tie |= eq > 1u ? (1u << r) : 0u;  // (eq counts the key itself once)
+                }
+                asm volatile("" ::: "memory");
+            }
         }
         // (this group's ranks are final HERE: left to itself the compiler sinks every group's compares to the end of the step,
         // keeps all the mates alive until then and spills them — one ds_read + s_waitcnt + scratch_store per key)
 #pragma unroll
-        for (int k = 0; k < H; k++)
-            if (h + k < ITEMS) asm volatile("" : "+v"(st[h + k]));
+        for (int k = 0; k < H; k++) {
+            if (h + k >= ITEMS) continue;
+            st[h + k] = res[k];
+            asm volatile("" : "+v"(st[h + k]));
+        }
         asm volatile("" : "+v"(tie)::"memory");
     }
 #endif
@@ -1060,7 +1079,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // 6400 keys (a pass size of the 512^2 schedule) fill 640 threads x 10 keys exactly, three workgroups to a CU (as in sort_rank4.hip)
-static int rank5w_threads(long n) { return n == 6400 ? 640 : (n > 5120 ? 1024 : 512); }
+// Workgroup shape by column length (profiles/r06_sort_experiments.md): 13 .. 16 keys per thread and as many workgroups per CU as
+// the LDS takes beat fewer, larger workgroups with 8 .. 10 keys per thread — 6400 keys: 448 threads x 15 keys, four workgroups
+// per CU, 281 us against 343 us for 640 x 10 x three.  Probe builds move the class boundaries' shapes with -DR5W_NT_*.
+#ifndef R5W_NT_A
+#define R5W_NT_A 256    // 2048 < n <= 4096: six workgroups of four wavefronts per CU (0.570 against 0.556 with 512 threads)
+#endif
+#ifndef R5W_NT_B
+#define R5W_NT_B 448    // 4096 < n <= 7168
+#endif
+#ifndef R5W_NT_C
+#define R5W_NT_C 1024   // 7168 < n <= 9216
+#endif
+#ifndef R5W_NT_D
+#define R5W_NT_D 1024   // 9216 < n <= 13312
+#endif
+static int rank5w_threads(long n) { return n <= 4096 ? R5W_NT_A : (n <= 7168 ? R5W_NT_B : (n <= 9216 ? R5W_NT_C : (n <= 13312 ? R5W_NT_D : 1024))); }
 
 bool rank5w_supported(const SortArgs& a) {
     if (!a.rng_lo || !a.rng_hi || !a.src_sorted || !a.out) return false;
@@ -1137,11 +1171,12 @@ static int launch_rank5w_nt(const SortArgs& a, int ncols, hipStream_t st) {
 }
 
 int launch_rank5w(const SortArgs& a, int ncols, hipStream_t st) {
-    switch (rank5w_threads(a.n)) {
-        case 512: return launch_rank5w_nt<512>(a, ncols, st);
-        case 640: return launch_rank5w_items<10, 640>(a, ncols, st);
-        default: return launch_rank5w_nt<1024>(a, ncols, st);
-    }
+    const int nt = rank5w_threads(a.n);
+    if (nt == R5W_NT_A) return launch_rank5w_nt<R5W_NT_A>(a, ncols, st);
+    if (nt == R5W_NT_B) return launch_rank5w_nt<R5W_NT_B>(a, ncols, st);
+    if (nt == R5W_NT_C) return launch_rank5w_nt<R5W_NT_C>(a, ncols, st);
+    if (nt == R5W_NT_D) return launch_rank5w_nt<R5W_NT_D>(a, ncols, st);
+    return launch_rank5w_nt<1024>(a, ncols, st);
 }
 
 #ifdef R5_PERSISTENT_VARIANT
