@@ -215,22 +215,38 @@ __global__ __launch_bounds__(1024) void chol_inv2_kernel(const float* __restrict
             const float* s1 = (roleL1 ? Ub : Wb) + base1 + l31;
             const int kmin = !act0 ? kb1 : (!act1 ? kb0 : (kb0 < kb1 ? kb0 : kb1));
             if (act0 || act1) {
-                // (all bounds are multiples of 32: four k pairs per trip, their twelve operands in flight together — one pair
-                // per trip waits for an L2 round trip in front of every MFMA)
-                for (int k = kmin; k < j0; k += 8) {
-                    const bool on0 = act0 && k >= kb0, on1 = act1 && k >= kb1;
-                    float a[4], b0[4], b1[4];
+                // All bounds are multiples of 32.  The operands of a trip (four k pairs: four LDS reads + eight reads of finished
+                // columns from L2) are requested one trip AHEAD, into the other of two register sets: the loop used to wait an L2
+                // round trip (~1 us) in front of every four MFMAs — half the kernel's time at C = 256 (round 6).  Both groups of
+                // the wave run every trip from kmin on: a group that is not active yet (W rows above the panel) or no longer
+                // (finished L rows) reads the zeros that were stored for it and adds them — same fma chains for every entry that
+                // is kept, same bits; the per-trip predicates cost more registers than the MFMAs they saved.
+                constexpr int KP = 4;
+                float b0[2][KP], b1[2][KP];  // (the LDS operand is read where it is used: its latency is a tenth of L2's)
+                auto request = [&](int buf, int k) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        a[u] = pan[(k + 2 * u + h) * CH_NB + l31];
-                        b0[u] = on0 ? s0[(size_t)(k + 2 * u + h) * NP] : 0.f;
-                        b1[u] = on1 ? s1[(size_t)(k + 2 * u + h) * NP] : 0.f;
+                    for (int u = 0; u < KP; u++) {
+                        b0[buf][u] = s0[(size_t)(k + 2 * u + h) * NP];
+                        b1[buf][u] = s1[(size_t)(k + 2 * u + h) * NP];
                     }
+                };
+                auto multiply = [&](int buf, int k) {
+                    float a[KP];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (on0) X = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], -b0[u], X, 0, 0, 0);
-                        if (on1) Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], -b1[u], Y, 0, 0, 0);
+                    for (int u = 0; u < KP; u++) a[u] = pan[(k + 2 * u + h) * CH_NB + l31];
+#pragma unroll
+                    for (int u = 0; u < KP; u++) {
+                        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], -b0[buf][u], X, 0, 0, 0);
+                        Y = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], -b1[buf][u], Y, 0, 0, 0);
                     }
+                };
+                int k = kmin;
+                if (k < j0) request(0, k);
+                for (; k < j0; k += 4 * KP) {   // two trips per round (bounds are multiples of 32 = 4 trips): set 0, then set 1
+                    request(1, k + 2 * KP);
+                    multiply(0, k);
+                    if (k + 4 * KP < j0) request(0, k + 4 * KP);
+                    multiply(1, k + 2 * KP);
                 }
             }
         }
