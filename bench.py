@@ -48,6 +48,36 @@ LATENCY_CLASSES = ("legacy_normals", "householder", "chol_inv", "ns_init", "cov_
 SIDE_STREAM_CLASSES = ("legacy_normals", "householder")
 
 
+class _ReplaySync:
+    """Stand-in for dist.StyleSync(spread=True) in a world of `world` ranks on ONE GPU: broadcast_known() records what the owning
+    rank computes and hands the recording back when this (emulated) rank is not the owner — the per-rank step of an N-GPU job
+    without the links (bench.py's textures_per_s_batch8_as_rank_of_8)."""
+    spread, src, always = True, 0, False
+
+    def __init__(self, device, world):
+        self.device, self.world, self.rank, self.store = device, world, 0, {}
+        self.bytes_moved = self.messages = 0
+
+    @property
+    def is_source(self):
+        return self.rank == self.src
+
+    def verify(self, block=False):
+        return None
+
+    def raise_deferred(self):
+        return None
+
+    def broadcast_known(self, tensors, shapes, src=None, defer=False):
+        key = (int(src), tuple(tuple(int(v) for v in sh) for sh in shapes))
+        if self.rank == src:
+            self.store[key] = [t.clone() for t in tensors]
+            return list(tensors)
+        if key not in self.store:   # (while recording: another owner's pass, not needed yet)
+            return [torch.zeros(sh, dtype=torch.float32, device=self.device) for sh in shapes]
+        return [t.clone() for t in self.store[key]]   # (a received payload is a fresh buffer every time, like the real exchange's)
+
+
 def synthetic_style(device, seed=0):
     """style/graffiti.jpg loads as [1,3,736,512] at --size 512 (util.py:29,33-42); same shape, smooth random content"""
     g = torch.Generator().manual_seed(seed)
@@ -88,10 +118,20 @@ def roofline_of(name, rec, traffic=None):
         achieved, peak, unit, bound = rec["flops"] / (ms * 1e9), PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "mfma"
     else:
         achieved, peak, unit, bound = rec["bytes"] / (ms * 1e6), PEAK_HBM_GBS, "GB/s", "hbm"
-    return {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": (round(traffic[name]) if traffic and traffic.get(name) else None),
-            "algorithmic_bytes": round(rec["bytes"] / launches), "launches": rec["launches"],
-            "avg_us": round(1e3 * ms / launches, 3)}
+    out = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+           "frac": round(achieved / peak, 4), "traffic": (round(traffic[name]) if traffic and traffic.get(name) else None),
+           "algorithmic_bytes": round(rec["bytes"] / launches), "launches": rec["launches"],
+           "avg_us": round(1e3 * ms / launches, 3)}
+    if bound == "hbm" and out["traffic"] is not None:
+        out["traffic_over_algorithmic"] = round(out["traffic"] / max(out["algorithmic_bytes"], 1), 3)
+        if out["traffic"] < 0.98 * out["algorithmic_bytes"]:
+            # (VERDICT r5 weak #4 / #10c) the counted bytes are right — every input element is read, every output element written —
+            # but not all of them reach HBM: a tensor the previous kernel has just written is read back from the 256 MB MALL / the L2
+            out["frac_note"] = ("frac = ALGORITHMIC bytes / time over the HBM peak (an effective bandwidth): the PMC HBM traffic is "
+                                "below the algorithmic bytes because inputs the previous kernel has just written are served by the "
+                                "MALL / L2; on the bytes that reach HBM the fraction is frac x traffic_over_algorithmic")
+            out["frac_hbm_traffic"] = round(out["frac"] * out["traffic_over_algorithmic"], 4)
+    return out
 
 
 def cpu_baseline(hist_mode, threads):
@@ -411,6 +451,9 @@ def main():
                             # source is the SHARED sorted style (L2-resident), so the compulsory HBM part is 8 of the 12
                             r["achieved_compulsory_hbm"] = round(r["achieved"] * 8.0 / 12.0, 3)
                             r["frac_compulsory_hbm"] = round(r["frac"] * 8.0 / 12.0, 4)
+                            r["frac_note"] = ("frac is on 12 B per element (SURVEY 8d's key + index accounting: column in, one source "
+                                              "order statistic in, column out); the kernel writes no index and the shared sorted "
+                                              "source is L2-resident: frac_compulsory_hbm counts the 8 bytes that must move")
                     for r in sk:
                         if r["kernel"] == "sort_columns":
                             r["note"] = ("the style's 256 columns, sorted once per iteration and shared by all textures: "
@@ -456,6 +499,38 @@ def main():
                 result["textures_per_s_batch8"] = {
                     "value": round(6 * 8 / (time.perf_counter() - t0), 3),
                     "config": f"8 independent textures per step (config 4's per-GPU shard), hist_mode={args.hist_mode}, otherwise the headline configuration; 6 timed steps"}
+                # The same shard AS A RANK OF AN 8-GPU JOB RUNS IT.  On one GPU the step above encodes the style side of all five
+                # passes itself (five one-image encodes: amortised over 64 textures they are 1.6 % of a step, over 8 textures a
+                # tenth); under `--total 64 --gpus 8` pass p's style side is encoded by rank p mod 8 and broadcast (dist.py,
+                # StyleSync(spread=True)): a rank encodes at most ONE and receives the rest.  Emulated here on one GPU: a hook
+                # with world = 8 whose exchanges hand back the tensors the owning rank would have sent (recorded once, before the
+                # timed steps; nothing crosses a link in this row — the RCCL broadcasts themselves, asynchronous and <= 12 MB, are
+                # NOT in it).  Timed as the rank that owns the LARGEST pass (rank 4: the slowest of the eight).
+                if world == 1 and not args.pca:
+                    sync = _ReplaySync(device, world=8)
+                    tex.style_sync = sync
+                    try:
+                        for r in range(min(5, tex.passes)):      # record: every pass's payload from its owner
+                            sync.rank = r
+                            tex.prefetch_style_sides((SIZE, SIZE), [style], None)
+                        sync.rank = min(4, tex.passes - 1)
+                        for _ in range(2):
+                            step8()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(6):
+                            step8()
+                        torch.cuda.synchronize()
+                        r8 = 6 * 8 / (time.perf_counter() - t0)
+                    finally:
+                        tex.style_sync = None
+                    result["textures_per_s_batch8_as_rank_of_8"] = {
+                        "value": round(r8, 3),
+                        "projected_8gpu_factor": round(8 * r8 / result["value"], 3) if B == 64 else None,
+                        "config": "the step above as rank 4 of `--total 64 --gpus 8` runs it: the style side of its own pass encoded, "
+                                  "the other four passes' taken as received from their owners (recorded payloads, no link traffic in "
+                                  "this row); projected_8gpu_factor = 8 x this / the one-GPU 64-texture rate (north star: >= 7.5) — a "
+                                  "projection from ONE GPU, the driver's SCALE run is the measurement"}
         if "fused" in args.other_modes.split(","):
             # labelled fast paths, NOT the headline.  cdf / sort: (m @ R^T) @ R' re-associated to m @ (R^T R'), one
             # feature-map GEMM per iteration instead of two; chol: the whole step as one affine map in un-rotated space
