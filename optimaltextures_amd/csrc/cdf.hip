@@ -184,9 +184,9 @@ __device__ __forceinline__ void hist_add(unsigned* h, float v, float lo, float h
     // 16-byte load instead of four exec-mask branches
     const unsigned inc = (v >= lo && v <= hi) ? 1u : 0u;
     const float a = (v - lo) * (float)kBins;
-    int pos = (int)(FAST ? div_by(a, range, inv) : __fdiv_rn(a, range));   // (the conversion saturates; NaN -> 0)
-    pos = pos > kBins - 1 ? kBins - 1 : pos;
-    pos = pos < 0 ? 0 : pos;
+    // clamped in the FLOAT domain (one v_med3_f32; NaN -> 0), then converted: a float -> int cast of NaN or of an out-of-range
+    // value is undefined in C++, and the two integer clamps it replaces were one instruction more
+    const int pos = (int)__builtin_amdgcn_fmed3f(FAST ? div_by(a, range, inv) : __fdiv_rn(a, range), 0.f, (float)(kBins - 1));
 #ifdef CDF_PROBE_NOATOMIC   // scripts/cdf_probe.hip: the binning arithmetic without its LDS atomic
     if (pos == 0x7fffffff) atomicAdd(&h[pos & 255], inc);
 #else
@@ -654,12 +654,64 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void cd
     }
     const float range = hu - hl;
     unsigned* h = sh[tid >> 6];
+    const int bin = tid & (kBins - 1);
+    const bool fast = div_by_ok(range);
+    const float inv = fast ? __fdiv_rn(1.0f, range) : 0.f;
+    unsigned hs = 0;
+    if (!src_range) {
+        // The column's range sticks out of the style's: the style's counts over the JOINT range are binned here (the shared
+        // histogram is over the style's own range).  Round 6: FIRST, while the target column is still on its way from HBM, four
+        // 16-byte loads in flight and the reciprocal-refinement quotient (the same counts as IEEE division) — it used to run behind
+        // the target's histogram as a one-load-in-flight loop with fdiv: 555-580 us per [64 x 256 x 16384] launch against 430-440
+        // for columns that take the shared histogram, and inside optex_ot_loop MOST columns stick out (a column matched under the
+        // previous rotation is not inside the style's range under the next): the bench's "in-loop gap" of the fused matcher.
+        // (Also built and measured, not kept: the style sorted once per call and thread k bisecting for the first value of bin k —
+        // the same counts, no binning at all, and SLOWER: 616 against 541 us, fourteen dependent L2 reads per workgroup are not
+        // hidden by its three or four neighbours; profiles/r06_cdf_inloop.md.)
+        const float* ps = a.s + (size_t)((a.src_n_seg == 1) ? 0 : seg) * a.sss + (size_t)c * a.lds;
+        if (a.vec_s) {
+            const float4* s4 = reinterpret_cast<const float4*>(ps);
+            const int nvs = (int)(a.ns / 4);
+            int i = tid;
+            if (fast) {
+                // loads in flight: four where the column's own registers set the budget anyway (16 vectors per thread), two
+                // for the short columns (their occupancy is worth more than the deeper queue)
+                constexpr int SU = NV >= 16 ? 4 : 2;
+#pragma unroll 1
+                for (; i + (SU - 1) * NT < nvs; i += SU * NT) {
+                    float4 q[SU];
+#pragma unroll
+                    for (int u = 0; u < SU; u++) q[u] = s4[i + u * NT];
+#pragma unroll
+                    for (int u = 0; u < SU; u++) {
+                        hist_add4<true>(h, q[u], hl, hu, range, inv);
+                        asm volatile("" ::: "memory");  // (one vector's four chains at a time)
+                    }
+                }
+#pragma unroll 1
+                for (; i < nvs; i += NT) hist_add4<true>(h, s4[i], hl, hu, range, inv);
+            } else {
+#pragma unroll 1
+                for (; i < nvs; i += NT) hist_add4<false>(h, s4[i], hl, hu, range, 0.f);
+            }
+#pragma unroll 1
+            for (long j = 4L * nvs + tid; j < a.ns; j += NT) hist_add<false>(h, ps[j], hl, hu, range);
+        } else {
+#pragma unroll 1
+            for (long j = tid; j < a.ns; j += NT) hist_add<false>(h, ps[j], hl, hu, range);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NW; k++) hs += sh[k][bin];
+        __syncthreads();
+        for (int i = tid; i < NW * kBins; i += NT) (&sh[0][0])[i] = 0u;
+        __syncthreads();
+    }
 #ifdef CDF_PROBE_NOHIST
     if (range == 12345.f) {
 #else
-    if (div_by_ok(range)) {
+    if (fast) {
 #endif
-        const float inv = __fdiv_rn(1.0f, range);
 #pragma unroll
         for (int k = 0; k < NV; k++)
             if (tid + NT * k < nv) hist_add4<true>(h, v[k], hl, hu, range, inv);
@@ -669,36 +721,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void cd
             if (tid + NT * k < nv) hist_add4<false>(h, v[k], hl, hu, range, 0.f);
     }
     __syncthreads();
-    const int bin = tid & (kBins - 1);
     unsigned ht = 0;
 #pragma unroll
     for (int k = 0; k < NW; k++) ht += sh[k][bin];
-    unsigned hs;
-    if (src_range) {
-        hs = a.shist[((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * kBins + bin];
-    } else {
-        const float* ps = a.s + (size_t)((a.src_n_seg == 1) ? 0 : seg) * a.sss + (size_t)c * a.lds;
-        __syncthreads();
-        for (int i = tid; i < NW * kBins; i += NT) (&sh[0][0])[i] = 0u;
-        __syncthreads();
-        // (a plain loop, one load in flight: inside optex_ot_loop this branch runs for the few columns whose range sticks out of
-        // the style's; unrolled like hist_chunk its registers were the kernel's)
-        if (a.vec_s) {
-            const float4* s4 = reinterpret_cast<const float4*>(ps);
-            const int nvs = (int)(a.ns / 4);
-#pragma unroll 1
-            for (int i = tid; i < nvs; i += NT) hist_add4<false>(h, s4[i], hl, hu, range, 0.f);
-#pragma unroll 1
-            for (long j = 4L * nvs + tid; j < a.ns; j += NT) hist_add<false>(h, ps[j], hl, hu, range);
-        } else {
-#pragma unroll 1
-            for (long j = tid; j < a.ns; j += NT) hist_add<false>(h, ps[j], hl, hu, range);
-        }
-        __syncthreads();
-        hs = 0;
-#pragma unroll
-        for (int k = 0; k < NW; k++) hs += sh[k][bin];
-    }
+    if (src_range) hs = a.shist[((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * kBins + bin];
     if (tid == 0) {   // (the joint range: the two-kernel pipeline leaves it here too)
         a.lo[col] = lo;
         a.hi[col] = hi;

@@ -5,6 +5,7 @@
 //   scripts/cdf_probe_<variant>.bin [n] [reps]
 #include "../optimaltextures_amd/csrc/cdf.hip"
 
+#include <algorithm>
 #include <vector>
 
 __global__ void fill_gauss(float* x, size_t n, unsigned seed) {
@@ -54,9 +55,19 @@ int main(int argc, char** argv) {
     hipMalloc(&shist, (size_t)C * 256 * 4); hipMalloc(&ws, wsb);
     fill_gauss<<<4096, 256>>>(x, (size_t)ncols * n, 1u);
     fill_gauss<<<1024, 256>>>(src, (size_t)C * ns, 7u);
-    std::vector<float> lo(C, -4.5f), hi(C, 4.5f);
+    // the style's range: +-4.5 contains every gaussian target column (joint range = style range: the SHARED style histogram is
+    // taken); a narrower one (argv[3]) makes the targets stick out, and every workgroup bins the style column itself
+    const float half = argc > 3 ? (float)atof(argv[3]) : 4.5f;
+    const bool sorted = argc > 4 && atoi(argv[4]) != 0;   // the style columns sorted (the round-6 bisection experiment; no effect on the shipping kernel)
+    std::vector<float> lo(C, -half), hi(C, half);
     hipMemcpy(smn, lo.data(), C * 4, hipMemcpyHostToDevice);
     hipMemcpy(smx, hi.data(), C * 4, hipMemcpyHostToDevice);
+    if (sorted) {
+        std::vector<float> hsrc((size_t)C * ns);
+        hipMemcpy(hsrc.data(), src, hsrc.size() * 4, hipMemcpyDeviceToHost);
+        for (int c = 0; c < C; c++) std::sort(hsrc.begin() + (size_t)c * ns, hsrc.begin() + (size_t)(c + 1) * ns);
+        hipMemcpy(src, hsrc.data(), hsrc.size() * 4, hipMemcpyHostToDevice);
+    }
     optex::col_minmax_launch(x, n, (long)C * n, n, C, S, cmn, cmx, 0);
     spread_parts<<<(ncols * parts + 255) / 256, 256>>>(cmn, cmx, pmn, pmx, C, parts, ncols);
     optex::col_hist_launch(src, ns, (long)C * ns, ns, C, 1, smn, smx, shist, 0);
