@@ -797,9 +797,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (g + j >= ITEMS) continue;
             const uint32_t below = __builtin_amdgcn_alignbyte(cw[j], 0u, st[g + j]);
             const uint32_t start = __builtin_amdgcn_sad_u8(below, 0u, gs[j]);
-            uint32_t cnt = __builtin_amdgcn_alignbyte(0u, cw[j], st[g + j]) << 24;
-            if (ragged(g + j)) cnt = valid(g + j) ? cnt : (1u << 24);
-            st[g + j] = ((st[g + j] & 0x00ff0000u) | start) | cnt;
+            // cnt (byte b & 3 of the counter word) on top, the arrival number where it is, zeros below: ONE v_perm_b32 of
+            // (counter byte in the low byte of the alignbyte result, arrival in byte 2 of st) instead of shift + and + or
+            uint32_t hi16 = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(0u, cw[j], st[g + j]), st[g + j], 0x04020c0cu);
+            if (ragged(g + j)) hi16 = valid(g + j) ? hi16 : (1u << 24);
+            st[g + j] = hi16 | start;
         }
 #pragma unroll
         for (int j = 0; j < G; j++)
