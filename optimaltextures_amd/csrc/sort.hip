@@ -195,8 +195,16 @@ static int launch_sort_items(SortArgs a, int ncols, int* flags, hipStream_t st) 
             ProfScope prof(MODE == SORT_EMIT ? KC_SORT : KC_SORT_MATCH, st, 0.0, per_elem * (double)a.n * ncols);
             // owner-ranked, float domain: over-provisioned 8-bit buckets where the shape allows it (sort_rank5.hip, round 6),
             // the 8-slot-window kernel otherwise (sort_rank4.hip) — both flag what they cannot take
-            if (MODE == SORT_MATCH && tl_call.sort_rank4 <= 0 && rank5w_supported(a)) {
-                if ((rc = launch_rank5w(a, ncols, st))) return rc;
+            if (tl_call.sort_rank4 <= 0 && rank5w_supported(MODE, a)) {
+                if ((rc = launch_rank5w(MODE, a, ncols, st))) return rc;
+                if (!a.rng_lo) {
+                    // No caller-given range = not the rotated pastiche of the hot loop: the columns may hold massive ties (the
+                    // zeros of un-rotated ReLU features), which the 8-bit counters flag and rank_match4_kernel ranks itself
+                    // (all-equal buckets by pixel index).  It takes the flagged columns only (30 us of empty workgroups per
+                    // launch otherwise) and un-flags the ones it ranks; what it cannot take either goes to the radix sweep.
+                    a.only_flagged = 1;
+                    if ((rc = launch_rank4(MODE, a, ncols, st))) return rc;
+                }
             } else if ((rc = launch_rank4(MODE, a, ncols, st))) return rc;
         }
     }

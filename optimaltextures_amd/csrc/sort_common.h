@@ -106,8 +106,9 @@ int sort_large(int mode, const SortArgs& a, int ncols, void* ws, hipStream_t st)
 // owner-ranked ranking-by-counting kernel in the float domain (sort_rank4.hip): mode = SORT_MATCH (the transport match) or
 // SORT_EMIT (sorted keys / pixel indices, optex_sort_columns)
 int launch_rank4(int mode, const SortArgs& a, int ncols, hipStream_t st);
-// the match with over-provisioned 8-bit buckets (sort_rank5.hip): caller-given range, 16-byte aligned rows, staged source
-bool rank5w_supported(const SortArgs& a);
-int launch_rank5w(const SortArgs& a, int ncols, hipStream_t st);
+// ranking with over-provisioned 8-bit buckets (sort_rank5.hip): 16-byte aligned rows, 2048 < n <= 16384; the match additionally a
+// staged source column
+bool rank5w_supported(int mode, const SortArgs& a);
+int launch_rank5w(int mode, const SortArgs& a, int ncols, hipStream_t st);
 
 }  // namespace optex

@@ -202,6 +202,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (threadIdx.x == 0) a.flags[blockIdx.x] = 1;  // never on this toolchain: the radix kernel would take every column
         return;
     }
+    // as the SECOND ranking kernel behind rank_match5w_kernel (sort.hip: calls whose columns may hold massive ties) only the
+    // columns that one flagged are taken, and a column ranked here is un-flagged again for the radix sweep
+    if (a.only_flagged && a.flags[blockIdx.x] == 0) return;  // (ranked by rank_match5w_kernel)
     SORT_PROBE(0);
     // ---- 0. the column (registers past the end hold a copy of a real key: harmless for min / max, and they stay out of
     //         every LDS update below through selects)
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 if (a.out_idx) a.out_idx[(size_t)col * n + e] = (uint32_t)e;
             }
         }
+        if (a.only_flagged && tid == 0) a.flags[col] = 0;
         return;
     }
     const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
@@ -766,6 +770,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 if (valid(r)) R4_LDS(uint32_t, SLOT_B + (ba[r] << 2)) = (uint32_t)elem(r);
             drain(a.out_idx);
         }
+        if (a.only_flagged && tid == 0) a.flags[col] = 0;
         SORT_PROBE(10);
         return;
     }
@@ -836,6 +841,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int r = 0; r < ITEMS; r++)
             if (valid(r)) o[r < 4 * Q ? ((r >> 2) * NT + tid9) * 4 + (r & 3) : r * NT + tid9] = v[r];
     }
+    if (a.only_flagged && tid == 0) a.flags[col] = 0;
     SORT_PROBE(10);
 }
 

@@ -62,7 +62,7 @@ struct R5 {
     static_assert(TAB_B % 8 == 0 && TIE_B % 16 == 0 && TIE_B + 12u * R5_TCAP <= GS_B && TAB_B + 8u * (RK_COARSE + 1) <= TIE_B, "layout");
 };
 
-enum { R5_M_BAD = 0, R5_M_TN = 2 };
+enum { R5_M_BAD = 0, R5_M_TN = 2, R5_M_HEAVY = 4 };
 
 __device__ __forceinline__ unsigned r5_wave_incl_scan(unsigned v) {
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
@@ -571,7 +571,7 @@ struct R5W {
     static_assert(NBK <= 65536 && QR * (NT / 64) <= 64 && 6 * QR >= ITEMS, "layout: 6 * NWRD bytes hold one 4-byte slot per key");
 };
 
-template <int ITEMS, int NT, bool FULL>
+template <int ITEMS, int NT, bool FULL, bool EMIT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void rank_match5w_kernel(SortArgs a) {
     using K = R5W<ITEMS, NT>;
     constexpr int NW = NT / 64, QR = K::QR, CAP = K::CAP;
@@ -607,8 +607,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     const int seg = col / a.C, c = col - seg * a.C;
     const float* src = a.keys + (size_t)((a.x_n_seg == 1) ? 0 : seg) * a.ss + (size_t)c * a.ld;
-    const float* ssrt = a.src_sorted + ((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * a.ns;
-    float* o = a.out + (size_t)seg * a.oss + (size_t)c * a.ldo;
+    // the match (a.out: out[pixel] = sorted source order statistic of its rank) or the sort itself (optex_sort_columns: keys and /
+    // or pixel indices by rank, contiguous [column, n]) — the ranking is the same; a template parameter all the same: with both
+    // epilogues in one kernel the keys stay alive to the end and the 16-key instantiation of the MATCH spills in its mate step
+    constexpr bool emit = EMIT;
+    const float* ssrt = emit ? nullptr : a.src_sorted + ((size_t)((a.src_n_seg == 1) ? 0 : seg) * a.C + c) * a.ns;
+    float* o = emit ? nullptr : a.out + (size_t)seg * a.oss + (size_t)c * a.ldo;
 
     float x[ITEMS];
     {
@@ -628,7 +632,53 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             x[r] = src[ragged(r) ? (e < n ? e : n - 1) : e];
         }
     }
-    const float lo = a.rng_lo[col], hi = a.rng_hi[col];
+    // The column's range: the caller's (optex_ot_loop: the rotation GEMM's epilogue took min / max of exactly these values — the
+    // barrier below is then passed while the column is still on its way) or the kernel's own reduction (v_min / v_max drop NaN:
+    // a wavefront that sees a non-finite key reports hi = +inf and the column goes to the radix kernel).
+    const bool own_range = a.rng_lo == nullptr;   // uniform
+    float lo = 0.f, hi = 0.f;
+    if (!own_range) {
+        lo = a.rng_lo[col];
+        hi = a.rng_hi[col];
+    } else {
+        // per thread: v_min3 / v_max3 over the keys; NaN (dropped by both) through the sum of x * 0; equal neighbours (tie-heavy columns
+        // — ReLU features before any rotation: half the keys are exactly 0 — overflow this kernel's 8-bit counters: the sooner they
+        // leave for rank_match4_kernel, which ranks an all-equal bucket by pixel index, the better)
+        float nf = 0.f;
+        uint32_t eqp = 0u;
+        lo = hi = x[0];
+#pragma unroll
+        for (int r = 1; r + 1 < ITEMS; r += 2) {
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(lo) : "v"(x[r]), "v"(x[r + 1]));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(hi) : "v"(x[r]), "v"(x[r + 1]));
+        }
+        if (ITEMS % 2 == 0) {
+            asm("v_min_f32 %0, %0, %1" : "+v"(lo) : "v"(x[ITEMS - 1]));
+            asm("v_max_f32 %0, %0, %1" : "+v"(hi) : "v"(x[ITEMS - 1]));
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) nf = __builtin_fmaf(x[r], 0.f, nf);
+#pragma unroll
+        for (int r = 0; r + 1 < ITEMS; r += 2) eqp |= (x[r] == x[r + 1]) ? 1u : 0u;
+        if (__any(!(nf == 0.f))) hi = __uint_as_float(R5_INF);
+        const uint32_t heavy = __popcll(__ballot(eqp != 0u)) >= 16 ? 1u : 0u;
+        // wavefront: DPP row shifts, then the two row broadcasts: lane 63 holds the result
+#define R5_DPP_STEP(ctrl, rmask)                                                                                          \
+        {                                                                                                                 \
+            const float pl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lo), __float_as_int(lo), ctrl, rmask, 0xf, false)); \
+            const float ph = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(hi), __float_as_int(hi), ctrl, rmask, 0xf, false)); \
+            asm("v_min_f32 %0, %0, %1" : "+v"(lo) : "v"(pl));                                                         \
+            asm("v_max_f32 %0, %0, %1" : "+v"(hi) : "v"(ph));                                                         \
+        }
+        R5_DPP_STEP(0x111, 0xf) R5_DPP_STEP(0x112, 0xf) R5_DPP_STEP(0x114, 0xf) R5_DPP_STEP(0x118, 0xf)
+        R5_DPP_STEP(0x142, 0xa) R5_DPP_STEP(0x143, 0xc)
+#undef R5_DPP_STEP
+        if (lane == 63) {
+            red[w] = __float_as_uint(lo);
+            red[16 + w] = __float_as_uint(hi);
+            red[32 + w] = heavy;
+        }
+    }
     // ---- 0. clear the counters, the coarse histogram, the flags
     {
         const int tz = otid();
@@ -637,6 +687,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     if (tid < RK_COARSE) c1[tid] = 0u;
     if (tid < 32) misc[tid] = tid >= 28 ? R5_INF : 0u;  // words 28 .. 31: +inf, what a key without that mate reads
+    if (own_range) {
+        __syncthreads();   // (the partial ranges; the cleared counters ride along: B0 below is then passed at once)
+        uint32_t nheavy = 0u;
+        lo = __uint_as_float(red[0]);
+        hi = __uint_as_float(red[16]);
+#pragma unroll
+        for (int kk = 0; kk < NW; kk += 4) {
+            const r5_v4u pl = R5_LDS(const r5_v4u, RED_B + kk * 4), ph = R5_LDS(const r5_v4u, RED_B + 64 + kk * 4),
+                         pe = R5_LDS(const r5_v4u, RED_B + 128 + kk * 4);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                if (kk + j + 1 < NW) {
+                    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(lo) : "v"(pl[j]), "v"(pl[j + 1]));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(hi) : "v"(ph[j]), "v"(ph[j + 1]));
+                    nheavy += pe[j] + pe[j + 1];
+                } else if (kk + j < NW) {
+                    asm("v_min_f32 %0, %0, %1" : "+v"(lo) : "v"(pl[j]));
+                    asm("v_max_f32 %0, %0, %1" : "+v"(hi) : "v"(ph[j]));
+                    nheavy += pe[j];
+                }
+            }
+        }
+        lo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(lo)));   // (the builtin takes an int: the bits, not the value)
+        hi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(hi)));
+        if (2u * nheavy >= (uint32_t)NW) {  // tie-heavy: rank_match4_kernel's (it ranks an all-equal bucket by pixel index)
+            if (tid == 0) a.flags[col] = 1;
+            return;
+        }
+    }
     if (!(hi < __uint_as_float(R5_INF)) || !(lo > -__uint_as_float(R5_INF))) {  // non-finite range: radix kernel
         if (tid == 0) a.flags[col] = 1;
         return;
@@ -646,7 +725,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (tid == 0) a.flags[col] = 1;
             return;
         }
-        for (int e = tid; e < n; e += NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+        // constant column: already sorted, rank = pixel index
+        if (emit) {
+            for (int e = tid; e < n; e += NT) {
+                if (a.out_keys) a.out_keys[(size_t)col * n + e] = lo;
+                if (a.out_idx) a.out_idx[(size_t)col * n + e] = (uint32_t)e;
+            }
+        } else {
+            for (int e = tid; e < n; e += NT) o[e] = ssrt[quantile_index((uint32_t)e, ns, (unsigned)n, a.inv_2nt)];
+        }
+        if (a.only_flagged && tid == 0) a.flags[col] = 0;
         return;
     }
     const float s1 = __fdiv_rn((float)RK_COARSE, hi - lo);
@@ -655,7 +743,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         return;
     }
     __syncthreads();  // B0: cleared (passed while the column is still on its way)
-    {
+    if (!own_range) {
         float nf = 0.f;
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) nf = __builtin_fmaf(x[r], 0.f, nf);
@@ -763,6 +851,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             incl[j] = r5_wave_incl_scan(tot[j]);
             if (lane == 63) red[j * NW + w] = incl[j];
         }
+        if (own_range) {
+            // Not the hot loop's rotated pastiche: a quantised column (a few hundred distinct values, dozens of keys in each of as many
+            // buckets — no 8-bit counter overflows) would walk its buckets key by key in step 7 (5.4 ms instead of 0.85 for [64 x 256]
+            // columns of 16384 keys) only to overflow the tie list at the end.  Threads that see a bucket of >= 16 keys are counted:
+            // 32 of them and the column goes to rank_match4_kernel now.  (One flat patch of <= 255 equal keys is one such thread.)
+            uint32_t m = 0u;
+#pragma unroll
+            for (int j = 0; j < QR; j++) m |= cq[j].x | cq[j].y | cq[j].z | cq[j].w;
+            const unsigned hv = (unsigned)__popcll(__ballot((m & 0xf0f0f0f0u) != 0u));
+            if (lane == 0 && hv != 0u) atomicAdd(&misc[R5_M_HEAVY], hv);
+        }
         __syncthreads();  // B4a
         const unsigned pv = lane < QR * NW ? red[lane] : 0u;
         const unsigned pi = r5_wave_incl_scan(pv);
@@ -777,7 +876,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
     }
     __syncthreads();  // B4
-    if (ovf) {
+    if (ovf || (own_range && misc[R5_M_HEAVY] >= 32u)) {
         if (tid == 0) a.flags[col] = 1;
         return;
     }
@@ -1010,9 +1109,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             asm volatile("" ::: "memory");
         }
     }
-    // the keys are dead: the sorted source column on its way into their registers
+    // (match) the keys are dead: the sorted source column on its way into their registers
     r5_v4f sv[K::SQ];
-    {
+    if (!emit) {
         const int ts = otid();
 #pragma unroll
         for (int q = 0; q < K::SQ; q++) {
@@ -1037,6 +1136,44 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             before += (jf == kf && (jk < kk || (jk == kk && tpix[u] < pix))) ? 1u : 0u;
         }
         tres[t] += before;
+    }
+    if (emit) {
+        // ---- 8E / 9E. sorted keys / pixel indices: every owner writes its key (then its pixel number) to slot[rank] — every slot
+        //               has been read — and the column leaves the LDS in order with 16-byte stores
+        __syncthreads();  // (the tie results)
+        if (tn != 0u) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if ((st[r] & R5_TAG) != 0u) st[r] = tres[st[r] & ~R5_TAG];
+        }
+        const int te = otid();
+        auto elem = [&](int r) { return r < 4 * Q ? ((r >> 2) * NT + te) * 4 + (r & 3) : r * NT + te; };
+        const size_t obase = (size_t)col * (size_t)n;
+        const bool ovec = (n % 4 == 0) && a.out_vec;
+        auto drain = [&](uint32_t* dst) {
+            __syncthreads();
+            if (ovec) {
+                for (int e = te * 4; e < n; e += NT * 4)
+                    *reinterpret_cast<r5_v4u*>(dst + obase + e) = R5_LDS(const r5_v4u, SLOT_B + ((uint32_t)e << 2));
+            } else {
+                for (int e = te; e < n; e += NT) dst[obase + e] = R5_LDS(const uint32_t, SLOT_B + ((uint32_t)e << 2));
+            }
+        };
+        if (a.out_keys) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if (valid(r)) R5_LDS(float, SLOT_B + ((st[r] & 0xffffu) << 2)) = x[r];
+            drain(reinterpret_cast<uint32_t*>(a.out_keys));
+        }
+        if (a.out_idx) {
+            if (a.out_keys) __syncthreads();  // the keys have left the slot array
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if (valid(r)) R5_LDS(uint32_t, SLOT_B + ((st[r] & 0xffffu) << 2)) = (uint32_t)elem(r);
+            drain(a.out_idx);
+        }
+        if (a.only_flagged && tid == 0) a.flags[col] = 0;
+        return;
     }
     // ---- 8. stage the source
     {
@@ -1098,14 +1235,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #endif
 static int rank5w_threads(long n) { return n <= 4096 ? R5W_NT_A : (n <= 7168 ? R5W_NT_B : (n <= 9216 ? R5W_NT_C : (n <= 13312 ? R5W_NT_D : 1024))); }
 
-bool rank5w_supported(const SortArgs& a) {
-    if (!a.rng_lo || !a.rng_hi || !a.src_sorted || !a.out) return false;
+// Can launch_rank5w take this call?  mode = SORT_MATCH (with or without a caller-given range) or SORT_EMIT (keys and / or pixel
+// indices).  Everything else stays with rank_match4_kernel.
+bool rank5w_supported(int mode, const SortArgs& a) {
     if (a.n <= 2048 || a.n > SORT_MAX_N) return false;
     const long nt = rank5w_threads(a.n), items = (a.n + nt - 1) / nt;
+    // 16-byte loads: rows on 16-byte boundaries; a keys-per-thread count without scalar rows needs whole quads
     if (a.ld % 4 != 0 || a.ss % 4 != 0 || (reinterpret_cast<uintptr_t>(a.keys) & 15u) != 0) return false;
-    if (a.ldo % 4 != 0 || a.oss % 4 != 0 || (reinterpret_cast<uintptr_t>(a.out) & 15u) != 0) return false;
     if (items % 4 == 0 && a.n % 4 != 0) return false;
     if (items < 4 || items > 16) return false;
+    if ((a.rng_lo == nullptr) != (a.rng_hi == nullptr)) return false;
+    if (mode == SORT_EMIT) return a.out_keys != nullptr || a.out_idx != nullptr;
+    if (!a.src_sorted || !a.out) return false;
+    if (a.ldo % 4 != 0 || a.oss % 4 != 0 || (reinterpret_cast<uintptr_t>(a.out) & 15u) != 0) return false;
     const long qr = (items * 3 + 15) / 16, nwrd = 4 * nt * qr;
     long sq = (6 * nwrd / 16 + nt - 1) / nt;
     if (sq > 4) sq = 4;
@@ -1125,10 +1267,16 @@ static void quantile_magic(SortArgs& a) {
     a.qshr = l - 2;
 }
 
-template <int ITEMS, int NT>
+template <int ITEMS, int NT, bool EMIT>
 static int launch_rank5w_items(const SortArgs& a0, int ncols, hipStream_t st) {
     SortArgs a = a0;
-    quantile_magic(a);
+    if (EMIT) {
+        a.out = nullptr;   // contiguous [column, n] outputs: 16-byte stores when the columns start on 16-byte boundaries
+        a.out_vec = (a.n % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out_keys) & 15u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.out_idx) & 15u) == 0) ? 1 : 0;
+    } else {
+        quantile_magic(a);
+    }
     const size_t lds = R5W<ITEMS, NT>::LDS;
     const bool full = a.n == (long)ITEMS * NT;
     auto go = [&](auto kern, DeviceOnce& once) {
@@ -1144,41 +1292,46 @@ static int launch_rank5w_items(const SortArgs& a0, int ncols, hipStream_t st) {
     int rc;
     if (full) {
         static DeviceOnce once;
-        rc = go(rank_match5w_kernel<ITEMS, NT, true>, once);
+        rc = go(rank_match5w_kernel<ITEMS, NT, true, EMIT>, once);
     } else {
         static DeviceOnce once;
-        rc = go(rank_match5w_kernel<ITEMS, NT, false>, once);
+        rc = go(rank_match5w_kernel<ITEMS, NT, false, EMIT>, once);
     }
     if (rc) return rc;
     return check_launch("rank_match5w_kernel");
 }
 
-template <int NT>
+template <int NT, bool EMIT>
 static int launch_rank5w_nt(const SortArgs& a, int ncols, hipStream_t st) {
     switch ((int)((a.n + NT - 1) / NT)) {
-        case 4: return launch_rank5w_items<4, NT>(a, ncols, st);
-        case 5: return launch_rank5w_items<5, NT>(a, ncols, st);
-        case 6: return launch_rank5w_items<6, NT>(a, ncols, st);
-        case 7: return launch_rank5w_items<7, NT>(a, ncols, st);
-        case 8: return launch_rank5w_items<8, NT>(a, ncols, st);
-        case 9: return launch_rank5w_items<9, NT>(a, ncols, st);
-        case 10: return launch_rank5w_items<10, NT>(a, ncols, st);
-        case 11: return launch_rank5w_items<11, NT>(a, ncols, st);
-        case 12: return launch_rank5w_items<12, NT>(a, ncols, st);
-        case 13: return launch_rank5w_items<13, NT>(a, ncols, st);
-        case 14: return launch_rank5w_items<14, NT>(a, ncols, st);
-        case 15: return launch_rank5w_items<15, NT>(a, ncols, st);
-        default: return launch_rank5w_items<16, NT>(a, ncols, st);
+        case 4: return launch_rank5w_items<4, NT, EMIT>(a, ncols, st);
+        case 5: return launch_rank5w_items<5, NT, EMIT>(a, ncols, st);
+        case 6: return launch_rank5w_items<6, NT, EMIT>(a, ncols, st);
+        case 7: return launch_rank5w_items<7, NT, EMIT>(a, ncols, st);
+        case 8: return launch_rank5w_items<8, NT, EMIT>(a, ncols, st);
+        case 9: return launch_rank5w_items<9, NT, EMIT>(a, ncols, st);
+        case 10: return launch_rank5w_items<10, NT, EMIT>(a, ncols, st);
+        case 11: return launch_rank5w_items<11, NT, EMIT>(a, ncols, st);
+        case 12: return launch_rank5w_items<12, NT, EMIT>(a, ncols, st);
+        case 13: return launch_rank5w_items<13, NT, EMIT>(a, ncols, st);
+        case 14: return launch_rank5w_items<14, NT, EMIT>(a, ncols, st);
+        case 15: return launch_rank5w_items<15, NT, EMIT>(a, ncols, st);
+        default: return launch_rank5w_items<16, NT, EMIT>(a, ncols, st);
     }
 }
 
-int launch_rank5w(const SortArgs& a, int ncols, hipStream_t st) {
+template <bool EMIT>
+static int launch_rank5w_mode(const SortArgs& a, int ncols, hipStream_t st) {
     const int nt = rank5w_threads(a.n);
-    if (nt == R5W_NT_A) return launch_rank5w_nt<R5W_NT_A>(a, ncols, st);
-    if (nt == R5W_NT_B) return launch_rank5w_nt<R5W_NT_B>(a, ncols, st);
-    if (nt == R5W_NT_C) return launch_rank5w_nt<R5W_NT_C>(a, ncols, st);
-    if (nt == R5W_NT_D) return launch_rank5w_nt<R5W_NT_D>(a, ncols, st);
-    return launch_rank5w_nt<1024>(a, ncols, st);
+    if (nt == R5W_NT_A) return launch_rank5w_nt<R5W_NT_A, EMIT>(a, ncols, st);
+    if (nt == R5W_NT_B) return launch_rank5w_nt<R5W_NT_B, EMIT>(a, ncols, st);
+    if (nt == R5W_NT_C) return launch_rank5w_nt<R5W_NT_C, EMIT>(a, ncols, st);
+    if (nt == R5W_NT_D) return launch_rank5w_nt<R5W_NT_D, EMIT>(a, ncols, st);
+    return launch_rank5w_nt<1024, EMIT>(a, ncols, st);
+}
+
+int launch_rank5w(int mode, const SortArgs& a, int ncols, hipStream_t st) {
+    return mode == SORT_MATCH ? launch_rank5w_mode<false>(a, ncols, st) : launch_rank5w_mode<true>(a, ncols, st);
 }
 
 #ifdef R5_PERSISTENT_VARIANT

@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             for (int kern = 0; kern < 3; kern++) {
-                if (kern == 2 && !optex::rank5w_supported(a)) { printf("n = %5ld ns = %5ld rank5w: not supported\n", n, ns); continue; }
+                if (kern == 2 && !optex::rank5w_supported(optex::SORT_MATCH, a)) { printf("n = %5ld ns = %5ld rank5w: not supported\n", n, ns); continue; }
 #ifdef R5_PERSISTENT_VARIANT
                 if (kern == 1 && !optex::rank5_supported(a)) { printf("n = %5ld ns = %5ld rank5: not supported\n", n, ns); continue; }
 #else
@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
 #ifdef R5_PERSISTENT_VARIANT
                     else if (kern == 1) optex::launch_rank5(a, ncols, 0);
 #endif
-                    else optex::launch_rank5w(a, ncols, 0);
+                    else optex::launch_rank5w(optex::SORT_MATCH, a, ncols, 0);
                     hipEventRecord(e1, 0);
                     hipError_t err = hipDeviceSynchronize();
                     if (err != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(err)); return 1; }
@@ -117,6 +117,78 @@ int main(int argc, char** argv) {
             printf("schedule-weighted (13/12/10/9/8 iterations), ns = %s, %-6s: %.2f ms per step, %.2f TB/s = %.3f of HBM peak\n",
                    ratio ? "23 n / 16" : "3 n / 4", kern == 2 ? "rank5w" : (kern ? "rank5" : "rank4"), tot_us[kern] * 1e-3, tot_bytes / (tot_us[kern] * 1e6),
                    tot_bytes / (tot_us[kern] * 1e6) / 8.0);
+    }
+    // ---- the sort itself (optex_sort_columns: keys + pixel indices by rank, SURVEY 8d's 12 B per element), own range: both kernels
+    for (int si = 0; si < 5 && (!only_n || sizes[si] == only_n); si++) {
+        const long n = sizes[si];
+        std::vector<float> h((size_t)ncols * n);
+        std::mt19937 g(11 + si);
+        std::normal_distribution<float> d(0.f, 1.f);
+        for (auto& v : h) v = d(g);
+        float *x, *ok;
+        uint32_t* oi;
+        int* flags;
+        hipMalloc(&x, h.size() * 4); hipMalloc(&ok, h.size() * 4); hipMalloc(&oi, h.size() * 4); hipMalloc(&flags, ncols * 4);
+        hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        optex::SortArgs a{};
+        a.keys = x; a.ld = n; a.ss = (long)C * n; a.n = n; a.C = C; a.x_n_seg = S;
+        a.out_keys = ok; a.out_idx = oi; a.flags = flags; a.ncols = ncols;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        std::vector<float> hlo(ncols), hhi(ncols);
+        for (int c2 = 0; c2 < ncols; c2++) {
+            const float* kc = h.data() + (size_t)c2 * n;
+            hlo[c2] = *std::min_element(kc, kc + n);
+            hhi[c2] = *std::max_element(kc, kc + n);
+        }
+        float *dlo2, *dhi2;
+        hipMalloc(&dlo2, ncols * 4); hipMalloc(&dhi2, ncols * 4);
+        hipMemcpy(dlo2, hlo.data(), ncols * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dhi2, hhi.data(), ncols * 4, hipMemcpyHostToDevice);
+        for (int kern = 0; kern < 5; kern++) {   // 0 rank4; rank5w: 1 own range, 2 given range, 3 keys only, 4 indices only
+            a.rng_lo = kern == 2 ? dlo2 : nullptr; a.rng_hi = kern == 2 ? dhi2 : nullptr;
+            a.out_keys = kern == 4 ? nullptr : ok; a.out_idx = kern == 3 ? nullptr : oi;
+            if (kern >= 1 && !optex::rank5w_supported(optex::SORT_EMIT, a)) continue;
+            hipMemset(ok, 0xff, h.size() * 4); hipMemset(oi, 0xff, h.size() * 4);
+            float best = 1e30f, ms = 0.f;
+            for (int it = 0; it < reps + 1; it++) {
+                hipMemset(flags, 0, ncols * 4);
+                hipEventRecord(e0, 0);
+                if (kern == 0) optex::launch_rank4(optex::SORT_EMIT, a, ncols, 0);
+                else optex::launch_rank5w(optex::SORT_EMIT, a, ncols, 0);
+                hipEventRecord(e1, 0);
+                hipDeviceSynchronize();
+                hipEventElapsedTime(&ms, e0, e1);
+                if (it > 0 && ms < best) best = ms;
+            }
+            std::vector<int> fl(ncols);
+            hipMemcpy(fl.data(), flags, ncols * 4, hipMemcpyDeviceToHost);
+            int bad = 0, nchecked = 0;
+            std::vector<float> gk(n);
+            std::vector<uint32_t> gi(n);
+            std::vector<int> idx(n);
+            for (int k = 0; k < ncheck; k++) {
+                const int col = (int)(((long)k * 2731 + 17) % ncols);
+                if (fl[col]) continue;
+                nchecked++;
+                hipMemcpy(gk.data(), ok + (size_t)col * n, n * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(gi.data(), oi + (size_t)col * n, n * 4, hipMemcpyDeviceToHost);
+                const float* kc = h.data() + (size_t)col * n;
+                std::iota(idx.begin(), idx.end(), 0);
+                std::stable_sort(idx.begin(), idx.end(), [&](int p, int q) { return kc[p] < kc[q]; });
+                for (long i = 0; i < n; i++)
+                    if ((a.out_idx && gi[i] != (uint32_t)idx[i]) || (a.out_keys && memcmp(&gk[i], &kc[idx[i]], 4) != 0)) {
+                        if (bad < 6) printf("    col %d rank %ld: got (pixel %u key %.9g) expected (pixel %d key %.9g)\n", col, i, gi[i], gk[i], idx[i], kc[idx[i]]);
+                        bad++;
+                    }
+            }
+            const double bytes = 12.0 * n * ncols;
+            printf("sort_columns (keys + indices) n = %5ld %-6s %8.1f us  %6.2f TB/s  %.3f of 8 TB/s   flagged %d, mismatches on %d checked columns %d%s\n", n,
+                   kern == 0 ? "rank4" : (kern == 1 ? "rank5w" : (kern == 2 ? "5w-rng" : (kern == 3 ? "5w-key" : "5w-idx"))), best * 1e3, bytes / (best * 1e9), bytes / (best * 1e9) / 8.0,
+                   std::accumulate(fl.begin(), fl.end(), 0), nchecked, bad, bad ? "   <-- WRONG" : "");
+            fflush(stdout);
+        }
+        hipFree(x); hipFree(ok); hipFree(oi); hipFree(flags); hipFree(dlo2); hipFree(dhi2);
     }
     // ---- adversarial columns, rank5 only, every column checked: [distribution][n]
     if (!only_n) {
@@ -167,10 +239,10 @@ int main(int argc, char** argv) {
                     a.rng_lo = dlo; a.rng_hi = dhi;
 #ifdef R5_PERSISTENT_VARIANT
                     for (int kern = 1; kern < 3; kern++)
-                    if (kern == 1 ? !optex::rank5_supported(a) : !optex::rank5w_supported(a)) {
+                    if (kern == 1 ? !optex::rank5_supported(a) : !optex::rank5w_supported(optex::SORT_MATCH, a)) {
 #else
                     for (int kern = 2; kern < 3; kern++)
-                    if (!optex::rank5w_supported(a)) {
+                    if (!optex::rank5w_supported(optex::SORT_MATCH, a)) {
 #endif
                         printf("adversarial n = %5ld ns = %5ld dist %d %s: not supported\n", n, ns, dist, kern == 1 ? "rank5" : "rank5w");
                     } else {
@@ -180,7 +252,7 @@ int main(int argc, char** argv) {
                         if (kern == 1) optex::launch_rank5(a, nc, 0);
                         else
 #endif
-                        optex::launch_rank5w(a, nc, 0);
+                        optex::launch_rank5w(optex::SORT_MATCH, a, nc, 0);
                         hipError_t err = hipDeviceSynchronize();
                         if (err != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(err)); return 1; }
                         std::vector<int> fl(nc);
