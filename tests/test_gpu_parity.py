@@ -446,7 +446,9 @@ def _sort_edge_columns(n, rng):
     return names, np.stack([cols[k] for k in names]).astype(np.float32)
 
 
-@pytest.mark.parametrize("n", [600, 2048, 5000, 16384])
+# (2049 .. 16384 keys: rank_match5w_kernel's EMIT epilogue and own range reduction first — every workgroup shape of
+# rank5w_threads: 256 / 448 / 1024 threads, whole and ragged columns — then rank_match4_kernel on what it flagged, then the radix sweep)
+@pytest.mark.parametrize("n", [600, 2048, 2560, 4096, 5000, 6400, 7170, 9216, 12544, 15041, 16384])
 def test_sort_edge_distributions_indices_bit_exact(dev, n):
     from optimaltextures_amd import ops
     names, x = _sort_edge_columns(n, np.random.default_rng(n + 1))
@@ -458,7 +460,7 @@ def test_sort_edge_distributions_indices_bit_exact(dev, n):
         assert biteq(keys[c].view(np.uint32), ok[c].view(np.uint32)), f"{name}: keys differ"
 
 
-@pytest.mark.parametrize("nt,ns", [(2048, 2048), (5000, 3100), (16384, 12288), (12544, 16384)])
+@pytest.mark.parametrize("nt,ns", [(2048, 2048), (5000, 3100), (16384, 12288), (12544, 16384), (4096, 4096), (6400, 4800), (9216, 6912)])
 def test_sort_match_edge_distributions_bit_exact(dev, nt, ns):
     from optimaltextures_amd import ops
     from optimaltextures_amd.ops import Seg
