@@ -153,9 +153,9 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const float* __restrict_
 //     -row[k] from L2, coalesced), the same k-ordered fma chain as the VALU loop of chol_inv_kernel — which spent its time on
 //     eight broadcast ds_read_b128 per 32 fmas.  The MFMA leaves a row's 32 values on lanes l and l + 32; sixteen
 //     v_permlane32_swap hand every thread its own row.
-//   phase B: the 32 x 32 diagonal block is factored by the 32 lanes that own its rows with wave-level synchronisation only;
-//     after ONE workgroup barrier every thread solves its row against the finished block without further barriers
-//     (chol_inv_kernel: two workgroup barriers per column, 64 per panel).
+//   phase B: the 32 x 32 diagonal block is factored by the wavefront that holds it, on the matrix core as well (round 6: one
+//     rank-1 MFMA per column, see below); after ONE workgroup barrier every thread solves its row against the finished block
+//     without further barriers (chol_inv_kernel: two workgroup barriers per column, 64 per panel).
 typedef float chx16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(1024) void chol_inv2_kernel(const float* __restrict__ A, long a_ss, int C, int NP,
@@ -250,6 +250,34 @@ __global__ __launch_bounds__(1024) void chol_inv2_kernel(const float* __restrict
                 }
             }
         }
+        // ---- phase B, step 1: the 32 x 32 diagonal block, by the wavefront that holds it — on the matrix core (round 6).  The
+        //      block T (symmetric) is X or Y as phase A left it: row c of T lies in ONE register (q = (c & 3) + 4 (c >> 3)) across
+        //      the 32 lanes of half (c >> 2) & 1.  Column c of the factor is that row over sqrt(T[c][c]) (one v_readlane), and the
+        //      rank-1 update T -= y y^T of the whole block is one v_mfma_f32_32x32x2_f32 (k = 1 operands zero): 32 dependent
+        //      {readlane, sqrt, divide, MFMA} instead of 496 LDS broadcasts + 496 fmas on one wavefront (7 us -> 3 us per panel).
+        //      Same fma chain per entry (updates in ascending column order, the product -y_i y_j), same sqrt and division: same bits.
+        const int gd = j0 / CH_NB;
+        if (wave == (gd >> 1)) {
+            auto diag = [&](chx16 T) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; c++) {
+                    const int hc = (c >> 2) & 1, qc = (c & 3) + 4 * (c >> 3);
+                    const float v = T[qc];
+                    const float tcc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), c + 32 * hc));
+                    const float d = sqrtf(tcc);
+                    const float y = __fdiv_rn(v, d);
+                    if (h == hc && l31 >= c) dg[l31 * (CH_NB + 1) + c] = (l31 == c) ? d : y;   // L[l31][c]
+                    if (c + 1 < CH_NB) {
+                        float up = y;   // the operand wants the vector on lanes 0 .. 31 (k = 0) and zeros on 32 .. 63 (k = 1)
+                        if (hc) up = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false)[1]);
+                        const float av = h ? 0.f : up;
+                        T = __builtin_amdgcn_mfma_f32_32x32x2f32(av, -av, T, 0, 0, 0);
+                    }
+                }
+            };
+            if (gd & 1) diag(Y);
+            else diag(X);
+        }
         // hand the rows to their threads: after the swap X[q] is column (q & 3) + 8 (q >> 2) and Y[q] that column + 4 of THIS
         // thread's row, on every lane (v_permlane32_swap exchanges X's upper 32 lanes with Y's lower 32)
         float acc[CH_NB];
@@ -258,24 +286,6 @@ __global__ __launch_bounds__(1024) void chol_inv2_kernel(const float* __restrict
             auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[q]), __float_as_uint(Y[q]), false, false);
             acc[(q & 3) + 8 * (q >> 2)] = __uint_as_float(sw[0]);
             acc[(q & 3) + 8 * (q >> 2) + 4] = __uint_as_float(sw[1]);
-        }
-        // ---- phase B, step 1: the diagonal block, by the 32 lanes that own rows j0 .. j0 + 31 (wave-level synchronisation:
-        //      the LDS operations of one wave execute in order)
-        const int gd = j0 / CH_NB;
-        if (wave == (gd >> 1)) {
-            const bool mine = h == (gd & 1);
-            float y[CH_NB];
-#pragma unroll
-            for (int c = 0; c < CH_NB; c++) {
-                float t = acc[c];
-#pragma unroll
-                for (int k = 0; k < c; k++) t = __builtin_fmaf(-y[k], dg[c * (CH_NB + 1) + k], t);
-                if (mine && l31 == c) dg[c * (CH_NB + 1) + c] = sqrtf(t);
-                asm volatile("" ::: "memory");  // (one wave: its LDS operations execute in program order; the compiler must not
-                y[c] = __fdiv_rn(t, dg[c * (CH_NB + 1) + c]);  //  keep dg in registers across these points)
-                if (mine && l31 > c) dg[l31 * (CH_NB + 1) + c] = y[c];
-                asm volatile("" ::: "memory");
-            }
         }
         __syncthreads();
         // ---- step 2: every row against the finished block, no barrier
@@ -305,6 +315,7 @@ static size_t chol_lds_bytes(int NP) { return ((size_t)(NP - CH_NB) * CH_NB + CH
 int chol_np(int C) { return (C + CH_NB - 1) / CH_NB * CH_NB; }
 
 bool chol_use_mfma = true;  // (internal, not ABI: scripts/chol_probe.hip times the two kernels against each other)
+int chol_mfma_min_panels = 2;   // (round 6, diagonal block on the matrix core: 28 against 32 us at two panels, 15 against 14 at one)
 
 // A [batch] (C x C, stride a_ss) -> U, Linv [batch, NP, NP]
 int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float* Linv, hipStream_t st) {
@@ -333,9 +344,9 @@ int launch_chol_inv(const float* A, long a_ss, int C, int batch, float* U, float
     }
     // 2/3 C^3 flop for the factor + inverse; reads A, writes two triangles
     ProfScope prof(KC_CHOL, st, (2.0 / 3.0) * (double)C * C * C * batch, 12.0 * (double)C * C * batch);
-    // the two kernels compute the same fma chains (bit-identical outputs, scripts/chol_probe.hip); the MFMA panel update pays
-    // from three panels on: 1.08x at C = 100, 1.24x at 256, 1.38x at 512 (batch 64), 0.78x at a single panel
-    if (chol_use_mfma && NP >= 3 * CH_NB)
+    // the two kernels compute the same fma chains (bit-identical outputs, scripts/chol_probe.hip); the MFMA kernel pays from
+    // two panels on: 1.13x at C = 64, 1.35x at 128, 1.56x at 256, 1.69x at 512 (batch 64), 0.96x at a single panel
+    if (chol_use_mfma && NP >= chol_mfma_min_panels * CH_NB)
         hipLaunchKernelGGL(chol_inv2_kernel, dim3(batch), dim3(2 * NP), lds, st, A, a_ss, C, NP, U, Linv);
     else
         hipLaunchKernelGGL(chol_inv_kernel, dim3(batch), dim3(2 * NP), lds, st, A, a_ss, C, NP, U, Linv);

@@ -16,7 +16,7 @@ constexpr int GT = 64;        // small Gram output tile (GT x GT), 4 waves as 2 
 constexpr int GT2 = 128;      // large tile: 4 waves as 2 x 2 of 64 x 64 (2 x 2 MFMA tiles): one LDS read per MFMA instead of two
 constexpr int GK = 32;        // pixels staged per chunk
 constexpr int GSTR = GK + 1;  // odd LDS row stride: conflict-free column reads
-constexpr int G_MAX_SPLITS = 64;
+constexpr int G_MAX_SPLITS = 64;   // pixel splits per segment ... (gram_split_cap: up to 512 where a partial is small against its pixels)
 
 __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ x, long ld, long seg_stride, long n,
                                                        int C, float* __restrict__ mu, int vec) {
@@ -39,6 +39,42 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) mu[col] = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n);
+}
+
+// The same for FEW long columns (one texture: 64 channels x 262144 pixels on 64 workgroups took 87 us): `P` workgroups per column
+// over pixel ranges of `chunk` (a multiple of 4) pixels, partial sums in double, finished in a fixed order by
+// mean_from_dparts_kernel.  grid (columns, P)
+__global__ __launch_bounds__(256) void col_sum_parts_kernel(const float* __restrict__ x, long ld, long seg_stride, long n, int C,
+                                                            long chunk, double* __restrict__ part, int vec) {
+    const int col = blockIdx.x, seg = col / C, c = col % C;
+    const long beg = (long)blockIdx.y * chunk, end = beg + chunk < n ? beg + chunk : n;
+    const float* p = x + (size_t)seg * seg_stride + (size_t)c * ld;
+    double s = 0.0;
+    if (vec) {
+        const long v0 = beg / 4, v1 = end / 4;   // beg is a multiple of 4; the last range ends at n
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (long i = v0 + threadIdx.x; i < v1; i += blockDim.x) {
+            const float4 v = p4[i];
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+        for (long i = v1 * 4 + threadIdx.x; i < end; i += blockDim.x) s += (double)p[i];
+    } else {
+        for (long i = beg + threadIdx.x; i < end; i += blockDim.x) s += (double)p[i];
+    }
+    s = wave_sum(s);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + col] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void mean_from_dparts_kernel(const double* __restrict__ part, int P, int ncols, long n,
+                                                               float* __restrict__ mu) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    double s = 0.0;
+    for (int q = 0; q < P; q++) s += part[(size_t)q * ncols + col];
+    mu[col] = (float)(s / (double)n);
 }
 
 // spatial mean of every (segment, channel) from the per-tile row sums the forward rotation GEMM left behind
@@ -418,8 +454,18 @@ __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n
     const int ri = upper ? i : j, rj = upper ? j : i;
     float sum = 0.f;
     const int s_beg = pool ? 0 : s, s_end = pool ? n_seg : s + 1;
-    for (int ss = s_beg; ss < s_end; ss++)
-        for (int k = 0; k < splits; k++) sum += part[((size_t)ss * splits + k) * C * C + (size_t)ri * C + rj];
+    for (int ss = s_beg; ss < s_end; ss++) {
+        const float* p = part + (size_t)ss * splits * C * C + (size_t)ri * C + rj;
+        int k = 0;
+        for (; k + 8 <= splits; k += 8) {   // eight partials in flight, added in the same fixed order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = p[(size_t)(k + u) * C * C];
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += v[u];
+        }
+        for (; k < splits; k++) sum += p[(size_t)k * C * C];
+    }
     float v = __fdiv_rn(sum, N);
     if (i == j) v = v + eps;
     cov[(size_t)s * C * C + (size_t)i * C + j] = v;
@@ -448,6 +494,16 @@ static int launch_tri(const float* x, long ld, long seg_stride, long n, int C, c
     return OPTEX_OK;
 }
 
+// How many pixel ranges a segment's Gram matrix may be split into.  64 where a C x C partial is large against the pixels it
+// covers (C = 256, n = 16384: 64 partials are already as many bytes as the feature map); up to 512 where it is small (round 6:
+// ONE texture, relu1_1, n = 262144 pixels of <= 64 PCA channels ran on 64 workgroups = a quarter of the chip, 150 us per launch).
+static int gram_split_cap(long n, int C) {
+    long cap = n / (8L * C);
+    if (cap < G_MAX_SPLITS) cap = G_MAX_SPLITS;
+    if (cap > 512) cap = 512;
+    return (int)cap;
+}
+
 static int gram_splits(long n, int C, int n_seg, bool big) {
     // 64-tiles: two blocks' worth of work per CU; 128-tiles (two resident blocks per CU, long blocks): about four rounds of
     // resident blocks, so that the last round's idle CUs cost a few per cent instead of a third
@@ -457,7 +513,8 @@ static int gram_splits(long n, int C, int n_seg, bool big) {
     long want = (target + (long)pairs * n_seg - 1) / ((long)pairs * n_seg);
     long maxs = (n + 1023) / 1024;
     if (want > maxs) want = maxs;
-    if (want > G_MAX_SPLITS) want = G_MAX_SPLITS;
+    const int cap = gram_split_cap(n, C);
+    if (want > cap) want = cap;
     if (want < 1) want = 1;
     return (int)want;
 }
@@ -468,9 +525,18 @@ using namespace optex;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// the split-K partials of the Gram kernels: every launch of <= n_seg segments and <= n pixels uses at most
+// s * min(cap, ceil(6 CUs / s)) partials (gram_splits / the whole-triangle kernel's count below), s = its segment count
 extern "C" size_t optex_linear_stats_ws_bytes(long n, int C, int n_seg) {
-    (void)n;
-    return align_up((size_t)n_seg * G_MAX_SPLITS * C * C * sizeof(float), 256);
+    const long cap = gram_split_cap(n, C), target = 6L * device_cu_count();
+    long most = 0;
+    for (long s = 1; s <= n_seg; s++) {
+        long per = (target + s - 1) / s;
+        if (per > cap) per = cap;
+        if (per < 1) per = 1;
+        if (s * per > most) most = s * per;
+    }
+    return align_up((size_t)most * C * C * sizeof(float), 256);
 }
 
 extern "C" int optex_linear_stats(const float* x, long ld, long seg_stride, long n, int C, int n_seg, int pool,
@@ -494,7 +560,21 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
                            C * n_seg, n, mu);
     } else {
         ProfScope prof(KC_MEAN, st, 0.0, 4.0 * (double)n * C * n_seg);
-        hipLaunchKernelGGL(col_mean_kernel, dim3(C * n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, vec);
+        // few long columns: several workgroups per column (their double partial sums borrow the head of the Gram workspace,
+        // which the Gram kernel behind them on the stream overwrites)
+        const long ncols = (long)C * n_seg;
+        long P = ncols < 2L * device_cu_count() ? n / 16384 : 1;
+        if (P > 16) P = 16;
+        if (P >= 2 && (size_t)P * ncols * sizeof(double) <= ws_bytes) {
+            const long chunk = ((n + P - 1) / P + 3) / 4 * 4;
+            double* dpart = static_cast<double*>(ws);
+            hipLaunchKernelGGL(col_sum_parts_kernel, dim3((unsigned)ncols, (unsigned)P), dim3(256), 0, st, x, ld, seg_stride, n, C,
+                               chunk, dpart, vec);
+            hipLaunchKernelGGL(mean_from_dparts_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, dpart, (int)P,
+                               (int)ncols, n, mu);
+        } else {
+            hipLaunchKernelGGL(col_mean_kernel, dim3(C * n_seg), dim3(256), 0, st, x, ld, seg_stride, n, C, mu, vec);
+        }
     }
     int rc = check_launch("col_mean_kernel");
     if (rc) return rc;
@@ -508,7 +588,8 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
         const long target = 2L * device_cu_count();
         long want = (target + n_seg - 1) / n_seg, maxs = (n + 255) / 256;
         want = want > maxs ? maxs : want;
-        splits = (int)(want > G_MAX_SPLITS ? G_MAX_SPLITS : (want < 1 ? 1 : want));
+        const long cap = gram_split_cap(n, C);
+        splits = (int)(want > cap ? cap : (want < 1 ? 1 : want));
     }
     long chunk = (n + splits - 1) / splits;
     chunk = (chunk + GK - 1) / GK * GK;  // chunk starts stay multiples of 4 pixels (float4 loads)

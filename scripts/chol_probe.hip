@@ -9,9 +9,10 @@
 #include <vector>
 
 int main() {
+    optex::chol_mfma_min_panels = 1;   // time the MFMA kernel at every size (the library switches at launch_chol_inv's threshold)
     std::mt19937 g(3);
     std::normal_distribution<float> d(0.f, 1.f);
-    for (int C : {23, 32, 64, 100, 128, 181, 256, 300, 512}) {
+    for (int C : {23, 32, 48, 64, 96, 100, 128, 181, 256, 300, 512}) {
         for (int batch : {1, 64}) {
             const int NP = optex::chol_np(C);
             std::vector<float> h((size_t)batch * C * C);
