@@ -387,6 +387,22 @@ int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O
     return gemm_tn_launch(a, OPTEX_PIXEL_MAJOR, OPTEX_PIXEL_MAJOR, st);
 }
 
+// A[b] @ B[b] with a leading dimension and matrix strides of its own on every operand (A: C x C inside rows of lda floats) — the
+// style-side factor times R^T for every iteration of a loop in one launch (ot_loop.hip, prepare_style)
+int small_gemm_nn_ld(const float* A, long lda, long a_ss, const float* B, long b_ss, float* O, long o_ss, int C, int batch,
+                     hipStream_t st) {
+    GemmArgs a;
+    a.At = B; a.lda = C; a.at_ss = b_ss;
+    a.B = A; a.ldb = lda; a.b_ss = a_ss;
+    a.O = O; a.ldo = C; a.o_ss = o_ss;
+    a.M = C; a.K = C; a.n = C; a.n_seg = batch;
+    a.bsub = nullptr; a.bsub_ss = 0; a.badd = nullptr; a.badd_ss = 0; a.content = nullptr; a.strength = 0.f;
+    a.epi = 0; a.alpha = 1.f; a.alpha_seg = nullptr; a.diag = 0.f; a.sym = 0;
+    a.prof_cls = KC_SMALL_GEMM;
+    a.rowstat = 0; a.rs_a = nullptr; a.rs_b = nullptr;
+    return gemm_tn_launch(a, OPTEX_PIXEL_MAJOR, OPTEX_PIXEL_MAJOR, st);
+}
+
 // Two independent batches of true products in ONE launch:  O1[b] = alpha alpha1[b] (A1[b] B1[b]),  O2[b] = alpha alpha2[b]
 // (A2[b] B2[b]),  b < batch — the Y W and W Z of a Newton-Schulz iteration (3 800 launches per sym-mode step were 2 500 of
 // these pairs going out one by one).

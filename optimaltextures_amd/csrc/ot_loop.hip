@@ -19,6 +19,8 @@ using namespace optex;
 namespace optex {
 int small_gemm(const float* At, long lda, long at_ss, const float* B, long ldb, long b_ss, float* O, long ldo, long o_ss, int C,
                int batch, bool epi, float alpha, const float* alpha_seg, float diag, hipStream_t st, bool sym);
+int small_gemm_nn_ld(const float* A, long lda, long a_ss, const float* B, long b_ss, float* O, long o_ss, int C, int batch,
+                     hipStream_t st);
 int small_gemm_nn(const float* A, long a_ss, const float* B, long b_ss, float* O, int C, int batch, float alpha,
                   const float* alpha_seg, float diag, const int* live_until, int live_idx, hipStream_t st);
 __global__ void rot_mean_kernel(const float* __restrict__ R, long r_ss, const float* __restrict__ mu, int mu_per_set, int C, int per,
@@ -217,24 +219,32 @@ int rotate_with_stats(const float* R, long r_ss, const float* x, float* y, int C
 
 // Transfer operator of one iteration, transposed (At[k][m] = T[m][k], what the apply GEMM takes), for every pastiche
 // segment: cov_t [n_seg, C, C] (eps included) against the rotated style statistics of iteration `it`.
-int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg, int Ss, int it, hipStream_t st) {
+// with_rt (chol / pca, prepare_style's hoisted products): the result is T^T R_it^T = (R_it T)^T, what the loop's apply GEMM takes,
+// written to `out` by the same single launch — the style-side factor arrives multiplied by R_it^T already (w.tmp_s).
+int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg, int Ss, int it, hipStream_t st,
+                       bool with_rt = false, float* out = nullptr) {
     const size_t cc = (size_t)C * C;
     const int NP = chol_np(C);
     const size_t pp = (size_t)NP * NP;
     int rc;
+    if (!out) out = w.At;
+    const float* pre = w.tmp_s + (size_t)it * Ss * cc;
     if (mode == MODE_CHOL) {
         // histmatch.py:24-27  T = L_s L_t^-1  ->  T^T = (L_t^-1)^T L_s^T = Linv_t^T @ U_s
         if ((rc = launch_chol_inv(cov_t, (long)cc, C, n_seg, w.Ut, w.Lt, st))) return rc;
+        if (with_rt)
+            return small_gemm(w.Lt, NP, (long)pp, pre, C, Ss > 1 ? (long)cc : 0, out, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f,
+                              st, false);
         const float* Us = w.Us + (size_t)it * Ss * pp;
-        return small_gemm(w.Lt, NP, (long)pp, Us, NP, Ss > 1 ? (long)pp : 0, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr,
+        return small_gemm(w.Lt, NP, (long)pp, Us, NP, Ss > 1 ? (long)pp : 0, out, C, (long)cc, C, n_seg, false, 1.f, nullptr,
                           0.f, st, false);
     }
     float *Y, *Z;
     if ((rc = ns_sqrt(cov_t, (long)cc, C, n_seg, kEps, w.ns_buf, &Y, &Z, st))) return rc;
     if (mode == MODE_PCA) {
         // histmatch.py:29-34  T = Q_s Q_t^-1  ->  T^T = Q_t^-1 Q_s   (both symmetric)
-        const float* Ys = w.Ys + (size_t)it * Ss * cc;
-        return small_gemm(Z, C, (long)cc, Ys, C, Ss > 1 ? (long)cc : 0, w.At, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
+        const float* Ys = with_rt ? pre : w.Ys + (size_t)it * Ss * cc;
+        return small_gemm(Z, C, (long)cc, Ys, C, Ss > 1 ? (long)cc : 0, out, C, (long)cc, C, n_seg, false, 1.f, nullptr, 0.f, st, false);
     }
     // histmatch.py:36-42  T = Q_t^-1 (Q_t S_s Q_t)^1/2 Q_t^-1   (symmetric: T^T = T)
     if ((rc = copy_async(w.Yt, Y, (size_t)n_seg * cc, st))) return rc;
@@ -254,8 +264,12 @@ int transfer_operators(int mode, LoopWs& w, const float* cov_t, int C, int n_seg
 // rotations are shared, one per pastiche segment when every segment has its own, r_ss != 0):
 //   cov_sr[it][g] = R_g,it^T cov(S_s(g)) R_g,it + eps I,   mu_sr[it][g] = R_g,it^T mu_s(g),   s(g) = g or 0
 // and the style-side factor of the mode (chol: U_s = L_s^T; pca: Q_s)
+// Rt32 != NULL (the default association of the loop, chol / pca): additionally tmp_s[it][g] = U_s R_it^T (Q_s R_it^T) — the
+// loop's apply GEMM takes (R T)^T = T^T R^T = Linv_t^T (U_s R^T): with the style-side product taken here for all iterations in
+// one batched launch, an iteration has ONE C x C product between its factorization and its apply GEMM instead of two
+// (493 launches of a single-texture call, 1.8 ms of a 64-texture chol step).  The same product in another association.
 int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int G, int C, const float* R32, long r_ss, int iters,
-                  hipStream_t st, void* stream) {
+                  hipStream_t st, void* stream, const float* Rt32 = nullptr) {
     const size_t cc = (size_t)C * C;
     int rc;
     if ((rc = optex_linear_stats(style, ns, (long)C * ns, ns, C, Ss, 0, 0.f, w.mu_s, w.cov_s, w.stats_ws, w.stats_ws_bytes, stream)))
@@ -273,11 +287,26 @@ int prepare_style(int mode, LoopWs& w, const float* style, long ns, int Ss, int 
     }
     hipLaunchKernelGGL(rot_mean_kernel, dim3(iters * G), dim3(256), 0, st, R32, r_ss, w.mu_s, Ss > 1 ? 1 : 0, C, G, w.mu_sr);
     if ((rc = check_launch("rot_mean_kernel"))) return rc;
-    if (mode == MODE_CHOL) return launch_chol_inv(w.cov_sr, (long)cc, C, iters * G, w.Us, w.Ls, st);
+    const int NP = chol_np(C);
+    const size_t pp = (size_t)NP * NP;
+    if (mode == MODE_CHOL) {
+        if ((rc = launch_chol_inv(w.cov_sr, (long)cc, C, iters * G, w.Us, w.Ls, st))) return rc;
+        if (Rt32)
+            for (int g = 0; g < G; g++)
+                if ((rc = small_gemm_nn_ld(w.Us + (size_t)g * pp, NP, (long)(pp * G), Rt32 + (size_t)g * r_ss, (long)cc,
+                                           w.tmp_s + (size_t)g * cc, (long)(cc * G), C, iters, st)))
+                    return rc;
+        return OPTEX_OK;
+    }
     if (mode == MODE_PCA) {
         float *Y, *Z;
         if ((rc = ns_sqrt(w.cov_sr, (long)cc, C, iters * G, kEps, w.ns_buf, &Y, &Z, st))) return rc;
-        return copy_async(w.Ys, Y, (size_t)iters * G * cc, st);
+        if ((rc = copy_async(w.Ys, Y, (size_t)iters * G * cc, st))) return rc;
+        if (Rt32)
+            for (int g = 0; g < G; g++)
+                if ((rc = small_gemm_nn_ld(w.Ys + (size_t)g * cc, C, (long)(cc * G), Rt32 + (size_t)g * r_ss, (long)cc,
+                                           w.tmp_s + (size_t)g * cc, (long)(cc * G), C, iters, st)))
+                    return rc;
     }
     return OPTEX_OK;
 }
@@ -290,7 +319,8 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
     const size_t cc = (size_t)C * C;
     const long xs = (long)C * n;
     int rc;
-    if ((rc = prepare_style(mode, w, style, ns, Ss, G, C, R32, r_ss, iters, st, stream))) return rc;
+    const bool with_rt = fused == 0 && (mode == MODE_CHOL || mode == MODE_PCA);
+    if ((rc = prepare_style(mode, w, style, ns, Ss, G, C, R32, r_ss, iters, st, stream, with_rt ? Rt32 : nullptr))) return rc;
     if (fused == 3) {
         // The whole chain in C x C algebra (no content blend): every step is x' = M_i (x - mean) + mu_s with
         // M_i = R_i T_i R_i^T, and the statistics the next step needs follow analytically,
@@ -348,12 +378,16 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
             if ((rc = linear_stats_parts(w.y, ldy, (long)C * ldy, n, C, n_seg, 0, kEps, w.mu_t, w.cov_t, w.stats_ws,
                                          w.stats_ws_bytes, sums ? w.rs_a : nullptr, w.rs_parts, stream)))
                 return rc;
-            if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, G, it, st))) return rc;   // At = T^T
             // histmatch.py:27/34/42,44 + optex.py:175, 115-117:  (T hist_t + mu_sr) @ R^T  evaluated as ONE feature-map GEMM
             //   x = (R T)(y - mu_t) + R mu_sr,   R mu_sr = R R^T mu_s = mu_s,   (R T)^T = T^T R^T = At @ Rt
             // — the same product in another association (a C x C GEMM instead of a second C x n one); the content blend
-            // rides in the epilogue as before.
-            if ((rc = small_gemm_nn(w.At, (long)cc, Rt, r_ss, w.M1, C, n_seg, 1.f, nullptr, 0.f, nullptr, 0, st))) return rc;
+            // rides in the epilogue as before.  chol / pca: T^T R^T comes out of transfer_operators' one product (prepare_style).
+            if (with_rt) {
+                if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, G, it, st, true, w.M1))) return rc;
+            } else {
+                if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, G, it, st))) return rc;   // At = T^T
+                if ((rc = small_gemm_nn(w.At, (long)cc, Rt, r_ss, w.M1, C, n_seg, 1.f, nullptr, 0.f, nullptr, 0, st))) return rc;
+            }
             if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream, ldy)))
                 return rc;
         } else if (fused == 2) {
