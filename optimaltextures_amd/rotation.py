@@ -4,6 +4,7 @@ matrices after np.random.seed(s); the O(N^3) Householder accumulation runs on th
 itself can run on the GPU too (DeviceNormals): same MT19937 words, same polar method and cache, advanced by
 optex_legacy_normals from numpy's own state tuple."""
 import os
+import warnings
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 
@@ -161,6 +162,17 @@ class DeviceNormals:
     def drop_pending(self):
         """forget prefetched rotations (a forward() that raised midway, a schedule that changed): the stream stays where the
         draws left it — the dropped values are consumed, exactly as if someone had asked for them and thrown them away"""
+        n_drawn = sum(int(c) for _, c, _, _ in self._queue)
+        if n_drawn:
+            # the numpy-compatible stream has moved past these draws: every later rotation differs from what the reference would
+            # draw for the same seed.  Counted, and said once per generator (ADVICE r5).
+            self.dropped_rotations = getattr(self, "dropped_rotations", 0) + n_drawn
+            if not getattr(self, "_warned_drop", False):
+                self._warned_drop = True
+                warnings.warn(f"DeviceNormals: {n_drawn} rotation(s) drawn ahead were discarded because the request sequence left the "
+                              "prefetched schedule; the gaussian stream has consumed them, so later rotations differ from the "
+                              "reference's sequence for this seed (further drops are counted in .dropped_rotations)",
+                              RuntimeWarning, stacklevel=3)
         self._queue.clear()
         self._feed = []
 

@@ -17,7 +17,7 @@ for name in ("bench_default.json", "bench_b64_cdf_kernel_summary.md", "bench_b64
              "sort_rank4_phases.log", "sort_time_probe.log", "sort_columns_microbench.log", "normals_probe.log",
              "batch_probe.log", "gram_probe.md", "ns_count_probe.md", "cdf_probe.log", "colcopy_probe.log", "b8_timeline_gaps.md",
              "b8_layout_probe.log", "cdf_fused_sq_counters.md", "sort_match5w_sq_counters.md", "sort5_probe.log", "chol_probe.log",
-             "sort_stress_loop.log"):
+             "sort_stress_loop.log", "sort_ties_probe.log", "glue_planar_probe.log", "pytest_gpu.log"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{pre}_{name}"))
 if not os.path.exists(os.path.join(src, "pmc_traffic_cdf.json")):

@@ -53,6 +53,9 @@ grep -E "^## |wave-instructions|ACTIVE_INST_VALU /" $OUT/sort_match5w_sq_counter
 grep -E "weighted" $OUT/sort5_probe.log; grep -c WRONG $OUT/sort5_probe.log
 ( echo "# optex_sort_columns / optex_sort_match at [64, 256, n] ($STAMP): scripts/microbench.py --only sort"; for n in 16384 9216 4096; do python scripts/microbench.py --only sort --S 64 --n $n --reps 5; done ) 2>&1 | grep -v "amdgpu.ids" > $OUT/sort_columns_microbench.log
 grep sort_kv $OUT/sort_columns_microbench.log | head -4
+( echo "# optex_sort_columns / optex_sort_match on rotated, quantised and half-zero columns ($STAMP): scripts/sort_ties_probe.py"; python scripts/sort_ties_probe.py 16384 9216 4096 ) 2>&1 | grep -v "amdgpu.ids" > $OUT/sort_ties_probe.log
+grep "sort_columns" $OUT/sort_ties_probe.log | head -3
+( echo "# optex_vgg_glue_layout, the transposing launches of a 64-texture step, alone ($STAMP): scripts/glue_planar_probe.py"; python scripts/glue_planar_probe.py ) 2>&1 | grep -v "amdgpu.ids" > $OUT/glue_planar_probe.log
 ( echo "# cdf_fused_kernel: shared style histogram (style range 4.5) vs style binned by every workgroup (3.0) ($STAMP): scripts/cdf_probe_ship.bin n 8 half"; for h in 4.5 3.0; do for n in 16384 12544 9216 6400 4096; do scripts/cdf_probe_ship.bin $n 8 $h; done; done ) 2>&1 | grep -v "amdgpu.ids" | grep -E "^#|shipping|behind" > $OUT/cdf_probe.log
 ( echo "# the two Cholesky + inverse kernels ($STAMP): scripts/chol_probe.bin"; scripts/chol_probe.bin ) 2>&1 | grep -v "amdgpu.ids" > $OUT/chol_probe.log
 ( timeout 1200 python scripts/sort_stress.py --loop 60 7 ) 2>&1 | grep -v "amdgpu.ids" > $OUT/sort_stress_loop.log; tail -1 $OUT/sort_stress_loop.log
