@@ -547,6 +547,9 @@ int device_cu_count();
 #ifndef R5W_BRANCHFREE
 #define R5W_BRANCHFREE 0   // 1: place / mate steps without exec-mask branches (selects + a +inf word): measured SLOWER (profiles/r06_sort_experiments.md)
 #endif
+#ifndef R5W_PACKED_T
+#define R5W_PACKED_T 0   // 1: count step with (x - lo) * s1 of two keys per v_pk_add_f32 / v_pk_mul_f32: measured SLOWER (0.541 against 0.548 weighted)
+#endif
 #ifndef R5W_G
 #define R5W_G 4     // keys whose LDS operations are in flight together in the count and decode steps
 #endif
@@ -805,11 +808,34 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         float fr[G];
         r5_v2f e2[G];
         uint32_t b[G], old[G];
+#if R5W_PACKED_T
+        // t = (x - lo) * s1 for two keys per instruction (v_pk_add_f32, v_pk_mul_f32: the same IEEE operations, same bits)
+        float tj[G];
+#pragma unroll
+        for (int j = 0; j < G; j += 2) {
+            if (g + j + 1 < ITEMS) {
+                r5_v2f xx = {x[g + j], x[g + j + 1]};
+                asm volatile("" : "+v"(xx));  // (keeps the differences x - lo from being formed ahead, next to the sample's)
+                x[g + j] = xx.x;
+                x[g + j + 1] = xx.y;
+                const r5_v2f t2 = (xx - r5_v2f{lo, lo}) * r5_v2f{s1, s1};
+                tj[j] = t2.x;
+                tj[j + 1] = t2.y;
+            } else if (g + j < ITEMS) {
+                asm volatile("" : "+v"(x[g + j]));
+                tj[j] = (x[g + j] - lo) * s1;
+            }
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < G; j++) {
             if (g + j >= ITEMS) continue;
+#if R5W_PACKED_T
+            const float t = tj[j];
+#else
             asm volatile("" : "+v"(x[g + j]));  // (keeps the differences x - lo from being formed ahead, next to the sample's)
             const float t = (x[g + j] - lo) * s1;
+#endif
             fr[j] = __builtin_amdgcn_fractf(t);
             e2[j] = R5_LDS(const r5_v2f, TAB_B + ((uint32_t)t << 3));
         }
