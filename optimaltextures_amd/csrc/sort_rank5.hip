@@ -1263,6 +1263,9 @@ static int rank5w_threads(long n) { return n <= 4096 ? R5W_NT_A : (n <= 7168 ? R
 
 // Can launch_rank5w take this call?  mode = SORT_MATCH (with or without a caller-given range) or SORT_EMIT (keys and / or pixel
 // indices).  Everything else stays with rank_match4_kernel.
+// (The library compiles this file twice — R5W_TU = 0: the match instantiations and everything else, R5W_TU = 1: the EMIT
+//  instantiations — so that the 156 kernels build side by side; a build without R5W_TU, e.g. a probe, holds everything.)
+#if !defined(R5W_TU) || R5W_TU == 0
 bool rank5w_supported(int mode, const SortArgs& a) {
     if (a.n <= 2048 || a.n > SORT_MAX_N) return false;
     const long nt = rank5w_threads(a.n), items = (a.n + nt - 1) / nt;
@@ -1281,6 +1284,8 @@ bool rank5w_supported(int mode, const SortArgs& a) {
     if (a.ns % 4 != 0 || (reinterpret_cast<uintptr_t>(a.src_sorted) & 15u) != 0 || a.ns > src_max) return false;
     return true;
 }
+
+#endif
 
 // floor(A / d) for every A < 2^30 as (A * m) >> (30 + l) with l = ceil(log2 d), m = ceil(2^(30 + l) / d) < 2^32 (Granlund &
 // Montgomery 1994, Theorem 4.2 for 30-bit dividends: 2^(30+l) <= m d <= 2^(30+l) + 2^l).  Here d = 2 n and
@@ -1356,9 +1361,15 @@ static int launch_rank5w_mode(const SortArgs& a, int ncols, hipStream_t st) {
     return launch_rank5w_nt<1024, EMIT>(a, ncols, st);
 }
 
+int launch_rank5w_emit(const SortArgs& a, int ncols, hipStream_t st);
+#if !defined(R5W_TU) || R5W_TU == 1
+int launch_rank5w_emit(const SortArgs& a, int ncols, hipStream_t st) { return launch_rank5w_mode<true>(a, ncols, st); }
+#endif
+#if !defined(R5W_TU) || R5W_TU == 0
 int launch_rank5w(int mode, const SortArgs& a, int ncols, hipStream_t st) {
-    return mode == SORT_MATCH ? launch_rank5w_mode<false>(a, ncols, st) : launch_rank5w_mode<true>(a, ncols, st);
+    return mode == SORT_MATCH ? launch_rank5w_mode<false>(a, ncols, st) : launch_rank5w_emit(a, ncols, st);
 }
+#endif
 
 #ifdef R5_PERSISTENT_VARIANT
 // Workgroup shape by column length: one 1024-thread workgroup per CU above 8192 keys, two of 512 threads down to 4097, four
