@@ -18,6 +18,7 @@ dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 style = synthetic_style(dev)
 m = OptimalTexture(size=512, iters=500, passes=5, hist_mode=sys.argv[2] if len(sys.argv) > 2 else "chol", layers=(5, 4, 3, 2, 1)).to(dev).eval()
+torch.backends.cudnn.benchmark = True   # like bench.py
 with torch.inference_mode():
     for rep in range(reps):
         m.rng = otdist.rotation_rng(0, rep)
