@@ -357,22 +357,41 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256 * WPE, 256 * WPE), amd
                 // four lane groups holding the other pixels of the same channel
                 const size_t pidx = ((size_t)seg * ra.tiles_n + pt) * (size_t)M + (size_t)m;
                 if (ROWSTAT == 1) {
+                    // Round 6: v_min3 / v_max3 written out (fminf / fmaxf on values that crossed a permlane swap brought a
+                    // canonicalising v_max x, x each), and BOTH statistics through ONE pair of swaps: rows 0 / 2 of the wave
+                    // carry the minimum, rows 1 / 3 the NEGATED maximum, so a single v_min folds either — 25 instead of 56
+                    // VALU instructions per row tile of a kernel that has one wavefront per SIMD (nothing hides them).
                     float mn = v[0][0], mx = v[0][0];
+                    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(v[0][1]), "v"(v[0][2]));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(v[0][1]), "v"(v[0][2]));
+                    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(v[0][3]), "v"(v[1][0]));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(v[0][3]), "v"(v[1][0]));
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            mn = fminf(mn, v[r][j]);
-                            mx = fmaxf(mx, v[r][j]);
+                    for (int r = 1; r < 4; r++) {
+                        if (r > 1) {
+                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(v[r][0]), "v"(v[r][1]));
+                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(v[r][0]), "v"(v[r][1]));
+                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(v[r][2]), "v"(v[r][3]));
+                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(v[r][2]), "v"(v[r][3]));
+                        } else {
+                            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(v[1][1]), "v"(v[1][2]));
+                            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(v[1][1]), "v"(v[1][2]));
+                            asm("v_min_f32 %0, %0, %1" : "+v"(mn) : "v"(v[1][3]));
+                            asm("v_max_f32 %0, %0, %1" : "+v"(mx) : "v"(v[1][3]));
                         }
-                    float p, q;
-                    rs_pair16(mn, p, q); mn = fminf(p, q);
-                    rs_pair16(mx, p, q); mx = fmaxf(p, q);
-                    rs_pair32(mn, p, q); mn = fminf(p, q);
-                    rs_pair32(mx, p, q); mx = fmaxf(p, q);
-                    if (kq == 0 && ok) {
-                        a.rs_a[pidx] = mn;
-                        a.rs_b[pidx] = mx;
+                    }
+                    const float nx = -mx;
+                    // (row0: mn, row1: -mx, row2: mn, row3: -mx) against (row1: mn ... ) of the neighbouring rows, then the halves
+                    const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mn), __float_as_uint(nx), false, false);
+                    float m = __uint_as_float(s16[0]);
+                    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(__uint_as_float(s16[1])));
+                    const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                    m = __uint_as_float(s32[0]);
+                    asm("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(__uint_as_float(s32[1])));
+                    // rows 0 / 2 now hold min over the 64 pixels, rows 1 / 3 minus the max: lane group kq = 0 stores one, kq = 1 the other
+                    if (kq < 2 && ok) {
+                        float* dst = kq == 0 ? a.rs_a : a.rs_b;
+                        dst[pidx] = kq == 0 ? m : -m;
                     }
                 } else {
                     float sm = 0.f;
