@@ -580,8 +580,10 @@ static int rs_launch_mk(const RsArgs& ra, dim3 grid, hipStream_t st) {
         else
             hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 2>), grid, dim3(256), 0, st, ra);
     } else if (a.badd || a.content) {
+        // (round 6: double-buffered accumulators here too — the bias / blend of a finished row tile leaves behind the next tile's
+        //  k-steps like the plain stores; the linear modes' apply GEMM takes this path with the centring folded into its bias)
         if ((MT == 4 && KS == 64) && a.K == 4 * KS)
-            hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1, 1, (MT == 4 && KS == 64)>), grid, dim3(256), 0, st, ra);
+            hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1, 1, (MT == 4 && KS == 64), (MT == 4 && KS == 64) && RS_DB != 0>), grid, dim3(256), 0, st, ra);
         else
             hipLaunchKernelGGL((gemm_rs_kernel<MT, KS, 0, 1>), grid, dim3(256), 0, st, ra);
     } else {

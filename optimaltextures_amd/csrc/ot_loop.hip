@@ -80,6 +80,7 @@ struct LoopWs {
     // per-tile row statistics of the rotated pastiche, written by the forward rotation GEMM's epilogue (GemmArgs::rowstat)
     float *rs_a = nullptr, *rs_b = nullptr;
     int rs_parts = 0;
+    float* bias = nullptr;   // [n_seg, C]: mu_s - (R T) mu_t, the folded centring of the apply GEMM (linear_loop)
     // cdf / sort with one rotation sequence for the whole batch: the style side of EVERY iteration is prepared before the
     // loop (one batched GEMM, one min / max or one sort launch for all of them) — `ys` then holds iters rotated copies
     bool hoist = false;
@@ -127,6 +128,7 @@ struct LoopWs {
             y = b.take<float>((size_t)n_seg * C * padded_ld(n));
             M1 = b.take<float>((size_t)n_seg * cc);
             if (rs_parts) rs_a = b.take<float>(rs_floats);
+            bias = b.take<float>((size_t)n_seg * C);
         } else if (fused == 2) {  // literal three-GEMM sequence
             y = b.take<float>(xs);
             y2 = b.take<float>(xs);
@@ -170,6 +172,37 @@ struct LoopWs {
 };
 
 int copy_async(float* dst, const float* src, size_t count, hipStream_t st) { return device_copy(dst, src, count, st); }
+
+// out[seg][m] = badd[m] - sum_k At[seg][k][m] * bsub[seg][k]: the apply GEMM's  At^T (y - bsub) + badd  is  At^T y + out  — the
+// centring as a per-row bias (accumulated in double: one rounding of the folded term).  grid (n_seg, ceil(C / 64)), block 256:
+// 64 columns x 4 interleaved k ranges, eight loads in flight per thread (one dependent L2 round trip per k made it 65 us)
+__global__ __launch_bounds__(256) void affine_bias_kernel(const float* __restrict__ At, long at_ss, const float* __restrict__ bsub,
+                                                          const float* __restrict__ badd, long badd_ss, int C,
+                                                          float* __restrict__ out) {
+    const int seg = blockIdx.x, ml = threadIdx.x & 63, kp = threadIdx.x >> 6, m = blockIdx.y * 64 + ml;
+    const float* A = At + (size_t)seg * at_ss;
+    const float* mu = bsub + (size_t)seg * C;
+    double acc = 0.0;
+    if (m < C) {
+        int k = kp;
+        for (; k + 28 < C; k += 32) {
+            float av[8], mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                av[u] = A[(size_t)(k + 4 * u) * C + m];
+                mv[u] = mu[k + 4 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += (double)av[u] * (double)mv[u];
+        }
+        for (; k < C; k += 4) acc += (double)A[(size_t)k * C + m] * (double)mu[k];
+    }
+    __shared__ double part[4][64];
+    part[kp][ml] = acc;
+    __syncthreads();
+    if (kp == 0 && m < C)
+        out[(size_t)seg * C + m] = (float)((double)badd[(size_t)seg * badd_ss + m] - ((part[0][ml] + part[1][ml]) + (part[2][ml] + part[3][ml])));
+}
 
 // feature-map GEMM with every option spelled out (the C ABI entry point with the loop's fixed layouts)
 int fgemm(const float* At, long at_ss, const float* B, float* O, int C, long n, int n_seg, const float* bsub, const float* badd,
@@ -388,7 +421,17 @@ int linear_loop(int mode, float* x, long n, int n_seg, const float* style, long 
                 if ((rc = transfer_operators(mode, w, w.cov_t, C, n_seg, G, it, st))) return rc;   // At = T^T
                 if ((rc = small_gemm_nn(w.At, (long)cc, Rt, r_ss, w.M1, C, n_seg, 1.f, nullptr, 0.f, nullptr, 0, st))) return rc;
             }
-            if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream, ldy)))
+            // Large maps (round 6): the centring rides as a per-row bias, x = (R T) y + (mu_s - (R T) mu_t), so that the apply GEMM is
+            // the R-stationary kernel's plain loop with a bias in its epilogue — centring inside the k-loop (a second operand
+            // stream and a subtraction per k-step) made it 685 us against 521 at [64, 256, 16384], 8.5 ms of a 64-texture chol
+            // step.  The same affine map, the subtraction taken once in double instead of per element.  Small maps (one texture's
+            // deep layers) keep the centring in the GEMM: there a launch costs more than the subtractions.
+            if ((double)n_seg * (double)n >= 262144.0) {
+                hipLaunchKernelGGL(affine_bias_kernel, dim3(n_seg, (C + 63) / 64), dim3(256), 0, st, w.M1, (long)cc, w.mu_t, w.mu_s,
+                                   (long)(Ss > 1 ? C : 0), C, w.bias);
+                if ((rc = check_launch("affine_bias_kernel"))) return rc;
+                if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, nullptr, w.bias, C, content, strength, stream, ldy))) return rc;
+            } else if ((rc = fgemm(w.M1, (long)cc, w.y, x, C, n, n_seg, w.mu_t, w.mu_s, Ss > 1 ? C : 0, content, strength, stream, ldy)))
                 return rc;
         } else if (fused == 2) {
             // the literal sequence, three feature-map GEMMs (kept for tests and comparisons)
