@@ -471,6 +471,55 @@ __global__ void cov_finalize_kernel(const float* __restrict__ part, int C, int n
     cov[(size_t)s * C * C + (size_t)i * C + j] = v;
 }
 
+// The same by upper blocks (round 6): one workgroup per upper GT x GT block sums its partials along the rows (coalesced), stores the
+// block, and stores the mirror image of an off-diagonal block through an LDS transpose.  cov_finalize_kernel read the lower
+// half of the matrix at the transposed address — one 4-byte element per 64-byte sector — and took 96 us per launch for 64
+// matrices of 256^2 (1.5 TB/s), 5.5 ms of a 64-texture chol step.  Same sums in the same order: same bits.
+// grid (upper blocks, pool ? 1 : n_seg)
+template <int GT_>
+__global__ __launch_bounds__(256) void cov_finalize_blocks_kernel(const float* __restrict__ part, int C, int n_seg, int splits, int pool,
+                                                                  float N, float eps, float* __restrict__ cov) {
+    const int nb = (C + GT_ - 1) / GT_;
+    int bi = 0, rest = blockIdx.x;   // upper blocks row by row: (0, 0 .. nb - 1), (1, 1 .. nb - 1), ...
+    while (rest >= nb - bi) {
+        rest -= nb - bi;
+        bi++;
+    }
+    const int bj = bi + rest, s = blockIdx.y;
+    __shared__ float t[GT_][GT_ + 1];
+    const int s_beg = pool ? 0 : s, s_end = pool ? n_seg : s + 1;
+    const size_t cc = (size_t)C * C;
+    for (int e = threadIdx.x; e < GT_ * GT_; e += 256) {
+        const int r = e / GT_, c = e % GT_, i = bi * GT_ + r, j = bj * GT_ + c;
+        float v = 0.f;
+        if (i < C && j < C) {
+            float sum = 0.f;
+            for (int ss = s_beg; ss < s_end; ss++) {
+                const float* p = part + (size_t)ss * splits * cc + (size_t)i * C + j;
+                int k = 0;
+                for (; k + 8 <= splits; k += 8) {   // eight partials in flight, added in the same fixed order
+                    float q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) q[u] = p[(size_t)(k + u) * cc];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sum += q[u];
+                }
+                for (; k < splits; k++) sum += p[(size_t)k * cc];
+            }
+            v = __fdiv_rn(sum, N);
+            if (i == j) v = v + eps;
+            cov[(size_t)s * cc + (size_t)i * C + j] = v;
+        }
+        t[r][c] = v;
+    }
+    if (bi == bj) return;
+    __syncthreads();
+    for (int e = threadIdx.x; e < GT_ * GT_; e += 256) {
+        const int r = e / GT_, c = e % GT_, i = bj * GT_ + r, j = bi * GT_ + c;   // the mirror block: row = a column of the upper one
+        if (i < C && j < C) cov[(size_t)s * cc + (size_t)i * C + j] = t[c][r];
+    }
+}
+
 int device_cu_count();
 bool gram_tri_enabled = true;  // (internal, not ABI: tests compare the whole-triangle kernel with the tile-pair kernel)
 
@@ -629,7 +678,15 @@ int optex::linear_stats_parts(const float* x, long ld, long seg_stride, long n, 
     if ((rc = check_launch("gram_kernel"))) return rc;
     const float N = pool ? (float)((double)n * n_seg) : (float)n;
     ProfScope prof(KC_COVFIN, st, 0.0, 4.0 * (double)C * C * n_seg * (splits + 1));
-    hipLaunchKernelGGL(cov_finalize_kernel, dim3((C + 255) / 256, C, pool ? 1 : n_seg), dim3(256), 0, st, part, C, n_seg,
-                       splits, pool, N, eps, tri ? 32 : GT, cov);
+    const int fgt = tri ? 32 : GT, fnb = (C + fgt - 1) / fgt;
+    if ((long)(fnb * (fnb + 1) / 2) * (pool ? 1 : n_seg) < 2L * device_cu_count()) {
+        // few matrices (one texture): one thread per element, a workgroup per row — more workgroups than blocks
+        hipLaunchKernelGGL(cov_finalize_kernel, dim3((C + 255) / 256, C, pool ? 1 : n_seg), dim3(256), 0, st, part, C, n_seg,
+                           splits, pool, N, eps, fgt, cov);
+    } else {
+        const dim3 grid((unsigned)(fnb * (fnb + 1) / 2), (unsigned)(pool ? 1 : n_seg));
+        if (tri) hipLaunchKernelGGL(cov_finalize_blocks_kernel<32>, grid, dim3(256), 0, st, part, C, n_seg, splits, pool, N, eps, cov);
+        else hipLaunchKernelGGL(cov_finalize_blocks_kernel<GT>, grid, dim3(256), 0, st, part, C, n_seg, splits, pool, N, eps, cov);
+    }
     return check_launch("cov_finalize_kernel");
 }
