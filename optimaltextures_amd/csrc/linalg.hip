@@ -450,7 +450,17 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
     double s = 0.0;
     if (cc % 4 == 0 && (reinterpret_cast<uintptr_t>(Ab) & 15) == 0) {
         const float4* A4 = reinterpret_cast<const float4*>(Ab);
-        for (int i = threadIdx.x; i < cc / 4; i += 256) {
+        int i = threadIdx.x;
+        for (; i + 7 * 256 < cc / 4; i += 8 * 256) {   // eight loads in flight, added in the same order (34 -> ~10 us at 64 x 256^2)
+            float4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[u] = A4[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                s += ((double)q[u].x * (double)q[u].x + (double)q[u].y * (double)q[u].y) +
+                     ((double)q[u].z * (double)q[u].z + (double)q[u].w * (double)q[u].w);
+        }
+        for (; i < cc / 4; i += 256) {
             const float4 v = A4[i];
             s += ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
         }
@@ -488,6 +498,19 @@ __global__ __launch_bounds__(256) void ns_init_kernel(const float* __restrict__ 
     float* Yb = Y + (size_t)b * cc;
     float* Zb = Z + (size_t)b * cc;
     const int rows = (C + NS_INIT_PARTS - 1) / NS_INIT_PARTS, r0 = part * rows, r1 = (r0 + rows < C) ? r0 + rows : C;
+    if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(Ab) & 15) == 0 && (reinterpret_cast<uintptr_t>(Yb) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(Zb) & 15) == 0) {
+        // 16-byte pieces: a wavefront per row, 64 lanes x 4 columns (the same IEEE divisions)
+        for (int r = r0 + (threadIdx.x >> 6); r < r1; r += 4)
+            for (int c = (threadIdx.x & 63) * 4; c < C; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(Ab + r * C + c);
+                *reinterpret_cast<float4*>(Yb + r * C + c) =
+                    make_float4(__fdiv_rn(v.x, fro), __fdiv_rn(v.y, fro), __fdiv_rn(v.z, fro), __fdiv_rn(v.w, fro));
+                *reinterpret_cast<float4*>(Zb + r * C + c) =
+                    make_float4(r == c ? 1.f : 0.f, r == c + 1 ? 1.f : 0.f, r == c + 2 ? 1.f : 0.f, r == c + 3 ? 1.f : 0.f);
+            }
+        return;
+    }
     for (int r = r0 + (threadIdx.x >> 6); r < r1; r += 4)       // (no integer division per element: it was most of this kernel)
         for (int c = threadIdx.x & 63; c < C; c += 64) {
             Yb[r * C + c] = __fdiv_rn(Ab[r * C + c], fro);
