@@ -678,4 +678,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        otdist.shutdown()   # every rank leaves together (no-op for a single process)

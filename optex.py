@@ -150,4 +150,7 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        otdist.shutdown()   # multi-rank runs: every rank leaves together (no-op for a single process)

@@ -303,6 +303,17 @@ def barrier():
         dist.barrier()
 
 
+def shutdown():
+    """Leave the job in step: a barrier, then the process group is destroyed explicitly.  A rank that simply exits while a peer
+    is still tearing down its backend can make that peer abort (seen with gloo: SIGABRT in rank 0 of a two-rank dry run, one
+    run in ten) — and the launcher then reports a failed job although the result line was printed."""
+    if dist.is_available() and dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+
+
 def all_gather_floats(value: float, device) -> List[float]:
     """every rank's value, in rank order (bench.py reports per-rank step times so a scaling loss can be located)"""
     if not dist.is_initialized():

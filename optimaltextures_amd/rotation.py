@@ -157,7 +157,9 @@ class DeviceNormals:
         schedule covered does not draw again — the draws were enqueued ahead of time, e.g. during the previous step"""
         want = [(int(n), int(c)) for n, c in schedule if c > 0]
         have = self.pending() + list(getattr(self, "_feed", []) or [])
-        return len(have) > 0 and have == want[:len(have)]
+        # ... and it was enqueued FOR this schedule (prefetch / begin_feed tag their queue): the leftover tail of another schedule
+        # that happens to equal this one's head is not a cover (ADVICE r5) — forward() then drops it (counted, warned) and draws
+        return len(have) > 0 and have == want[:len(have)] and getattr(self, "_tag", None) == tuple(want)
 
     def drop_pending(self):
         """forget prefetched rotations (a forward() that raised midway, a schedule that changed): the stream stays where the
@@ -175,6 +177,7 @@ class DeviceNormals:
                               RuntimeWarning, stacklevel=3)
         self._queue.clear()
         self._feed = []
+        self._tag = None
 
     # ---- a schedule fed piece by piece: the draws of the NEXT call released one (pass, layer) at a time by the CURRENT call, each
     # at the start of one of its VGG codec phases (driver.OptimalTexture.forward, `rng_next`).  All at once (prefetch) the
@@ -185,6 +188,7 @@ class DeviceNormals:
         """start a fed schedule: nothing is enqueued yet; feed_one() releases the entries in order, finish_feed() the rest"""
         self.drop_pending()
         self._feed = [(int(n), int(c)) for n, c in schedule if c > 0]
+        self._tag = tuple(self._feed)
         self._fed_bytes = 0
 
     def feeding(self) -> bool:
@@ -229,6 +233,7 @@ class DeviceNormals:
         rotations of 256^2, 27 ms that would otherwise sit between the convolutions and every OT loop).  Leftovers of an
         earlier schedule are dropped first; at most PREFETCH_BYTES of rotations are kept ahead."""
         self.drop_pending()
+        self._tag = tuple((int(n), int(c)) for n, c in schedule if c > 0)
         held = 0
         for N, count in schedule:
             if count > 0:
